@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: I/Q frames/s of the batched VT-CNN2 forward on MI355X.
+
+Contract (one JSON line on rank 0):  python bench.py --gpus N --steps K --warmup W
+For N>1 the driver launches one process per GPU with torch.distributed.run; frames are
+independent, so each rank runs the same per-GPU batch on its own shard with NO data-path
+collective ("scaling": "weak"); the only torch.distributed calls are the barriers around
+the timed region and the MAX of the elapsed time.
+
+A "step" = one pass of the hot path (conv -> ... -> softmax -> argmax) over one batch of
+synthetic frames already resident in HBM.  Default workload = the configuration
+BASELINE.json's metric is quoted on: canonical VT-CNN2 (11 classes), batch 2^20, bf16 MFMA
+with f32 accumulation (configs[2]).  Other BASELINE configs that fit one GPU are run as
+short `extra` legs (not the headline value):  --workload selects any of them as headline.
+
+roofline: the dominant kernel's algorithmic FLOPs (MFMA-bound nets) or bytes (HBM-bound
+nets) per launch / its mean launch duration, measured with HIP events recorded inside
+mdc_forward on the launch stream in a separate, untimed pass.
+cpu_baseline: the numpy oracle ("port": a CPU restatement, NOT Keras -- Keras/TensorFlow
+are not installed) timed on this box's host cores on a bounded sample; rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0                                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}  # dense MFMA peaks (no sparsity)
+
+WORKLOADS = {
+    # name: (topology kind, filters, classes, dtype, per-GPU frames, weights)
+    "vtcnn2-c11-bf16-n2^20": ("vtcnn2", 256, 11, "bf16", 1 << 20, "synthetic seed 2016"),
+    "vtcnn2-c3-f32-n65536": ("vtcnn2", 256, 3, "f32", 1 << 16, "synthetic seed 2016"),
+    "vtcnn2-c11-f32-n65536": ("vtcnn2", 256, 11, "f32", 1 << 16, "synthetic seed 2016"),
+    "deployed3-f32-n2^20": ("deployed", 3, 3, "f32", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),
+    "deployed10-f32-n2^20": ("deployed", 10, 3, "f32", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),
+}
+DEFAULT = "vtcnn2-c11-bf16-n2^20"
+EXTRAS = ["vtcnn2-c3-f32-n65536", "deployed3-f32-n2^20", "deployed10-f32-n2^20"]
+
+
+def make_model(name, device):
+    from modulationdetectioncnn_amd import VTCNN2, Topology
+    kind, filters, classes, dtype, n, _ = WORKLOADS[name]
+    if kind == "vtcnn2":
+        m = VTCNN2.synthetic(Topology.vtcnn2(classes), seed=2016, device=device, dtype=dtype)
+    else:
+        g = os.path.join(ROOT, "tests", "golden", "weights")
+        f = "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"
+        m = VTCNN2.from_npz(os.path.join(g, f), device=device, dtype=dtype)
+    return m, n, dtype
+
+
+def dominant_roofline(m, x, probs, labels, steps):
+    """Untimed profiling pass: per-kernel HIP-event time -> roofline object of the dominant kernel."""
+    import torch
+    topo = m.topology
+    m.set_profiling(True)
+    for _ in range(steps):
+        m.forward_device(x, probs=probs, labels=labels)
+    torch.cuda.synchronize()
+    prof = m.read_profile()
+    m.set_profiling(False)
+    name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+    n = x.shape[0]
+    launches_per_step = max(1, cnt // steps)
+    frames_per_launch = n / launches_per_step
+    avg_ms = ms / cnt
+    kernels = {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] // steps} for k, v in prof.items()}
+    if topo.kind == "vtcnn2":
+        flops = {"mdc_vt_conv": topo.conv_flops_per_frame, "mdc_vt_dense1": 2 * 10560 * 256,
+                 "mdc_vt_head": 2 * 256 * topo.classes}[name] * frames_per_launch
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[m.dtype]
+        rl = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+              "frac": ach / peak, "traffic": None, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
+    else:
+        by = topo.io_bytes_per_frame * frames_per_launch
+        ach = by / (avg_ms * 1e-3) / 1e9
+        rl = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
+    return rl, kernels
+
+
+def cpu_baseline(name, budget_s=20.0):
+    """Numpy oracle on the host cores, bounded sample of the same workload (same seeds)."""
+    from modulationdetectioncnn_amd import synthetic_frames
+    from oracle import oracle_np as O        # checker / baseline only
+    kind, filters, classes, dtype, n, _ = WORKLOADS[name]
+    from modulationdetectioncnn_amd import VTCNN2, Topology
+    if kind == "vtcnn2":
+        w = VTCNN2.synthetic(Topology.vtcnn2(classes), seed=2016).get_weights()
+        sample = 512
+    else:
+        g = os.path.join(ROOT, "tests", "golden", "weights")
+        f = "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"
+        w = VTCNN2.from_npz(os.path.join(g, f)).get_weights()
+        sample = 65536
+    x = synthetic_frames(sample, seed=2016)
+    O.forward(kind, x[: max(1, sample // 8)], w, dtype=np.float32)        # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        O.forward(kind, x, w, dtype=np.float32)
+        done += sample
+        el = time.perf_counter() - t0
+        if el > budget_s * 0.5 or done >= 16 * sample:
+            break
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": done / el, "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"{done} frames ({done // sample} x {sample}) of {name}, numpy f32 oracle (CPU restatement, not Keras), {el:.1f} s"}
+
+
+def run_workload(name, device, steps, warmup, dist=None):
+    import torch
+    from modulationdetectioncnn_amd import synthetic_frames
+    m, n, dtype = make_model(name, device)
+    rank = dist.get_rank() if dist else 0
+    x = synthetic_frames(n, seed=2016 + rank, device=f"cuda:{device}")
+    probs = torch.empty((n, m.topology.classes), dtype=torch.float32, device=x.device)
+    labels = torch.empty((n,), dtype=torch.int32, device=x.device)
+    for _ in range(warmup):
+        m.forward_device(x, probs=probs, labels=labels)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.forward_device(x, probs=probs, labels=labels)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=x.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return m, x, probs, labels, n, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    else:
+        device = 0
+    torch.cuda.set_device(device)
+    rank = dist.get_rank() if dist else 0
+    ngpu = world if dist else 1
+    if args.gpus != ngpu and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={ngpu}: launch with torch.distributed.run", file=sys.stderr)
+
+    name = args.workload
+    kind, filters, classes, dtype, _, weights = WORKLOADS[name]
+    m, x, probs, labels, n, el = run_workload(name, device, args.steps, args.warmup, dist)
+    total_frames = n * ngpu * args.steps
+    out = {
+        "metric": "I/Q frames/sec (2x128, VT-CNN2, batch=2^20)", "value": total_frames / el, "unit": "frames/s",
+        "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16"}[dtype],
+        "data": "synthetic N(0,5e-3) f32 frames resident in HBM; " + weights,
+        "config": {"workload": name, "topology": kind, "classes": classes, "frames_per_gpu": n,
+                   "global_batch": n * ngpu, "parallelism": f"batch-shard x{ngpu} (no collective)",
+                   "outputs": "softmax probabilities f32 + argmax int32"},
+    }
+    if rank == 0:
+        rl, kernels = dominant_roofline(m, x, probs, labels, max(2, min(args.steps, 5)))
+        out["roofline"] = rl
+        out["kernels"] = kernels
+    del m, x, probs, labels
+    torch.cuda.empty_cache()
+    if rank == 0 and ngpu == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(name)
+        if not args.no_extras:
+            extras = []
+            for en in EXTRAS:
+                if en == name:
+                    continue
+                try:
+                    em, ex, ep, elab, en_n, eel = run_workload(en, device, 5, 2)
+                    erl, _ = dominant_roofline(em, ex, ep, elab, 3)
+                    extras.append({"workload": en, "value": en_n * 5 / eel, "unit": "frames/s", "ms_per_step": eel / 5 * 1e3,
+                                   "dtype": WORKLOADS[en][3], "roofline": erl})
+                    del em, ex, ep, elab
+                    torch.cuda.empty_cache()
+                except Exception as e:     # an extra leg never hides the headline
+                    extras.append({"workload": en, "error": repr(e)})
+            out["extra"] = extras
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/* mdc.h -- C ABI of libmdc.so: MI355X (gfx950) inference path for the VT-CNN2-family
+ * modulation classifiers of peteroh23/ModulationDetectionCNN.
+ *
+ * The reference has no FFI/plugin interface; its boundary is the Keras object surface
+ * (citations into /root/reference):
+ *     model = models.Sequential(); model.add(...)      cnn.py:104-115, CNN.ipynb cell 6,
+ *                                                      RML2016.10a_VTCNN2_example.ipynb:229-243
+ *     model.load_weights(filepath)                     cnn.py:147, CNN.ipynb cell 8
+ *     model.predict(X, batch_size=...)                 cnn.py:198, cnn.py:237, CNN.ipynb cell 12
+ *     Model(inputs, outputs=model.layers[i].output)    CNN.ipynb cell 17 (layer taps)
+ *     int(np.argmax(test_Y_hat[i,:]))                  cnn.py:209 (first maximum wins)
+ * Each entry point below names the call it replaces.  INTEGRATION.md shows the ctypes
+ * binding (modulationdetectioncnn_amd/_cabi.py is that binding).
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * errno-style code and sets a thread-local message (mdc_last_error); nothing aborts,
+ * nothing throws across the boundary.  All device buffers belong to the caller; the
+ * library owns only the packed weights.  mdc_forward is asynchronous on the caller's HIP
+ * stream and performs no device synchronisation.  A finalized model is immutable and
+ * mdc_forward on it is re-entrant (one model per device; any number of streams).
+ */
+#ifndef MDC_H
+#define MDC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDC_ABI_VERSION 1
+
+/* error codes (negative errno values) */
+#define MDC_OK        0
+#define MDC_EINVAL   (-22)
+#define MDC_ENOMEM   (-12)
+#define MDC_ENODEV   (-19)
+#define MDC_ENOTSUP  (-95)
+#define MDC_EIO      (-5)     /* a HIP runtime call failed; see mdc_last_error() */
+#define MDC_ESTATE   (-1)     /* call out of order (e.g. forward before finalize) */
+
+/* Topology families.  Input is always (n, 2, 128) float32 I/Q. */
+enum {
+    MDC_KIND_DEPLOYED = 1,  /* CNN.ipynb cell 6: pad(0,1) Conv2D(F,(1,2)) relu Flatten Dense(C,relu) softmax;
+                               F = filters in {3,10}, C = 3.  Layers: 0 conv, 1 dense.             */
+    MDC_KIND_VTCNN2   = 2,  /* RML2016.10a_VTCNN2_example.ipynb:229-243: pad(0,2) Conv(256,1x3) relu
+                               pad(0,2) Conv(80,2x3) relu Flatten Dense(256,relu) Dense(C) softmax.
+                               Layers: 0 conv1, 1 conv2, 2 dense1, 3 dense2.  C <= 32.             */
+    MDC_KIND_CNNPY    = 3   /* cnn.py:104-115 literal model (H=1,W=2,C=128 under channels_last):
+                               pad(0,1) Conv2D(F,(1,2)) relu Flatten Dense(D,relu) Dense(C) softmax.
+                               Layers: 0 conv, 1 dense1, 2 dense2.                                 */
+};
+
+/* Arithmetic type of the matrix products (accumulation is always f32). */
+enum { MDC_F32 = 0, MDC_BF16 = 1, MDC_FP8 = 2 };
+
+/* Layer taps of CNN.ipynb cell 17.  tap_dev receives, per frame:
+ *   MDC_TAP_CONV   model4: last conv+ReLU output in the reference's layout
+ *                  (deployed: (2,129,F) channels_last; vtcnn2: (80,132) channels_first)
+ *   MDC_TAP_FLAT   model3: Flatten output (same values, same order as CONV)
+ *   MDC_TAP_DENSE  model2: output of the last Dense before softmax
+ *                  (deployed: post-ReLU (C); vtcnn2/cnnpy: logits (C))
+ *   MDC_TAP_HIDDEN vtcnn2/cnnpy only: Dense1+ReLU output                                   */
+enum { MDC_TAP_NONE = 0, MDC_TAP_CONV = 1, MDC_TAP_FLAT = 2, MDC_TAP_DENSE = 3, MDC_TAP_HIDDEN = 4 };
+
+typedef struct mdc_topology {
+    int32_t kind;        /* MDC_KIND_*                                                       */
+    int32_t filters;     /* deployed: F (3 or 10); cnnpy: F (10); vtcnn2: ignored (256/80)    */
+    int32_t hidden;      /* cnnpy: D (10); vtcnn2: ignored (256); deployed: ignored           */
+    int32_t classes;     /* C                                                                */
+    int32_t reserved[4]; /* must be 0                                                        */
+} mdc_topology;
+
+typedef struct mdc_model mdc_model;   /* opaque, owned by the library */
+
+int mdc_abi_version(void);
+
+/* models.Sequential() + model.add(...): describe the net.  `device` is the HIP ordinal. */
+int mdc_create(const mdc_topology* topo, int device, mdc_model** out);
+
+/* Number of weighted layers and the element counts load_weights must supply for each. */
+int mdc_num_layers(const mdc_model* m);
+int mdc_layer_sizes(const mdc_model* m, int layer, size_t* kernel_elems, size_t* bias_elems);
+
+/* model.load_weights(): one call per weighted layer, host pointers in the Keras layout
+ * (deployed/cnnpy conv: HWIO; vtcnn2 conv: OIHW; dense: (in, out) with `in` in the
+ * reference's Flatten order).  The data is copied; the caller keeps ownership.            */
+int mdc_set_weights(mdc_model* m, int layer, const float* kernel_host, size_t kernel_elems,
+                    const float* bias_host, size_t bias_elems);
+
+/* Pack the weights into the kernels' register/LDS/MFMA layouts and upload them.
+ * After this the model is immutable.  dtype: MDC_F32 | MDC_BF16 (MDC_FP8: ENOTSUP for now). */
+int mdc_finalize(mdc_model* m, int dtype);
+
+/* Bytes of caller-owned device scratch mdc_forward needs for n frames (0 for deployed). */
+size_t mdc_workspace_bytes(const mdc_model* m, int64_t n);
+
+/* model.predict(X) (+ np.argmax): x_dev (n,2,128) f32 contiguous on the model's device.
+ * probs_dev (n,C) f32 or NULL; labels_dev (n) int32 or NULL (first-max tie-break);
+ * tap_dev NULL unless tap != MDC_TAP_NONE.  Enqueued on hip_stream (NULL = null stream). */
+int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n,
+                float* probs_dev, int32_t* labels_dev,
+                float* tap_dev, int tap,
+                void* workspace_dev, size_t workspace_bytes,
+                void* hip_stream);
+
+/* Measurement support (bench.py roofline leg): when on, mdc_forward brackets each kernel
+ * launch with HIP events on the launch stream; mdc_profile_read synchronises on them and
+ * returns the summed device time and launch count of kernel slot `slot` since the last
+ * mdc_profile_reset.  Off by default; never on in the timed region of the headline number. */
+int mdc_set_profiling(mdc_model* m, int on);
+int mdc_profile_slots(const mdc_model* m);
+const char* mdc_profile_name(const mdc_model* m, int slot);
+int mdc_profile_read(mdc_model* m, int slot, double* total_ms, int64_t* launches);
+int mdc_profile_reset(mdc_model* m);
+
+const char* mdc_last_error(void);
+void mdc_destroy(mdc_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDC_H */

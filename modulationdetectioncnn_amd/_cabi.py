@@ -1,0 +1,81 @@
+"""ctypes binding of libmdc.so (include/mdc.h).  This is the stub INTEGRATION.md shows.
+
+The product path has no CPU fallback: if the shared library is missing, cannot be
+loaded, or reports no gfx950 device, the calls below raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdc.so")
+
+KIND_DEPLOYED, KIND_VTCNN2, KIND_CNNPY = 1, 2, 3
+F32, BF16, FP8 = 0, 1, 2
+TAP_NONE, TAP_CONV, TAP_FLAT, TAP_DENSE, TAP_HIDDEN = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "mdc_abi_version", "mdc_create", "mdc_num_layers", "mdc_layer_sizes", "mdc_set_weights",
+    "mdc_finalize", "mdc_workspace_bytes", "mdc_forward", "mdc_set_profiling", "mdc_profile_slots",
+    "mdc_profile_name", "mdc_profile_read", "mdc_profile_reset", "mdc_last_error", "mdc_destroy",
+]
+
+
+class MdcTopology(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("filters", C.c_int32), ("hidden", C.c_int32),
+                ("classes", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class MdcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libmdc error {code}: {msg}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libmdc.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m modulationdetectioncnn_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+    L.mdc_abi_version.restype = i32
+    L.mdc_create.argtypes = [C.POINTER(MdcTopology), i32, C.POINTER(vp)]
+    L.mdc_num_layers.argtypes = [vp]
+    L.mdc_layer_sizes.argtypes = [vp, i32, C.POINTER(sz), C.POINTER(sz)]
+    L.mdc_set_weights.argtypes = [vp, i32, C.POINTER(C.c_float), sz, C.POINTER(C.c_float), sz]
+    L.mdc_finalize.argtypes = [vp, i32]
+    L.mdc_workspace_bytes.argtypes = [vp, i64]
+    L.mdc_workspace_bytes.restype = sz
+    L.mdc_forward.argtypes = [vp, vp, i64, vp, vp, vp, i32, vp, sz, vp]
+    L.mdc_set_profiling.argtypes = [vp, i32]
+    L.mdc_profile_slots.argtypes = [vp]
+    L.mdc_profile_name.argtypes = [vp, i32]
+    L.mdc_profile_name.restype = C.c_char_p
+    L.mdc_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.mdc_profile_reset.argtypes = [vp]
+    L.mdc_last_error.restype = C.c_char_p
+    L.mdc_destroy.argtypes = [vp]
+    L.mdc_destroy.restype = None
+    for name in ("mdc_create", "mdc_num_layers", "mdc_layer_sizes", "mdc_set_weights", "mdc_finalize",
+                 "mdc_forward", "mdc_set_profiling", "mdc_profile_slots", "mdc_profile_read", "mdc_profile_reset"):
+        getattr(L, name).restype = i32
+    if L.mdc_abi_version() != 1:
+        raise RuntimeError(f"libmdc.so ABI version {L.mdc_abi_version()} != 1; rebuild it")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise MdcError(rc, lib().mdc_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,260 @@
+// C-ABI shim of libmdc.so (see include/mdc.h for the contract and the reference call
+// each entry point replaces).  No torch types, no exceptions across the boundary.
+#include "mdc_internal.h"
+
+#include <cstring>
+#include <new>
+
+namespace mdc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int upload(mdc_model* m, int idx, const void* host, size_t bytes) {
+    if (m->d_pack[idx]) {
+        (void)hipFree(m->d_pack[idx]);
+        m->d_pack[idx] = nullptr;
+    }
+    MDC_HIP(hipMalloc(&m->d_pack[idx], bytes));
+    MDC_HIP(hipMemcpy(m->d_pack[idx], host, bytes, hipMemcpyHostToDevice));
+    m->pack_bytes[idx] = bytes;
+    return MDC_OK;
+}
+
+ProfScope::ProfScope(const mdc_model* mm, int slot_, hipStream_t s_) : m(const_cast<mdc_model*>(mm)), slot(slot_), s(s_) {
+    if (!m->profiling) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) == hipSuccess) {
+        (void)hipEventRecord(e, s);
+        m->slots[slot].ev.push_back(e);
+    }
+}
+ProfScope::~ProfScope() {
+    if (!m->profiling) return;
+    if (m->slots[slot].ev.size() % 2 == 1) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) == hipSuccess) {
+            (void)hipEventRecord(e, s);
+            m->slots[slot].ev.push_back(e);
+        } else {
+            hipEvent_t b = m->slots[slot].ev.back();
+            (void)hipEventDestroy(b);
+            m->slots[slot].ev.pop_back();
+        }
+    }
+}
+
+}  // namespace mdc
+
+using namespace mdc;
+
+static int layer_layout(mdc_model* m) {
+    const mdc_topology& t = m->topo;
+    switch (t.kind) {
+        case MDC_KIND_DEPLOYED:
+            if (t.filters != 3 && t.filters != 10) { set_error("deployed: filters must be 3 or 10 (got %d)", t.filters); return MDC_ENOTSUP; }
+            if (t.classes != 3) { set_error("deployed: classes must be 3 (got %d)", t.classes); return MDC_ENOTSUP; }
+            m->nlayers = 2;
+            m->nk[0] = 2 * (size_t)t.filters;            m->nb[0] = t.filters;
+            m->nk[1] = 258 * (size_t)t.filters * t.classes; m->nb[1] = t.classes;
+            m->slots = {{"mdc_deployed_fwd"}};
+            return MDC_OK;
+        case MDC_KIND_VTCNN2:
+            if (t.classes < 2 || t.classes > 32) { set_error("vtcnn2: classes must be in 2..32 (got %d)", t.classes); return MDC_ENOTSUP; }
+            m->nlayers = 4;
+            m->nk[0] = (size_t)kC1 * 3;               m->nb[0] = kC1;
+            m->nk[1] = (size_t)kC2 * kC1 * 2 * 3;     m->nb[1] = kC2;
+            m->nk[2] = (size_t)kFeat * kHid;          m->nb[2] = kHid;
+            m->nk[3] = (size_t)kHid * t.classes;      m->nb[3] = t.classes;
+            m->slots = {{"mdc_vt_conv"}, {"mdc_vt_dense1"}, {"mdc_vt_head"}};
+            return MDC_OK;
+        case MDC_KIND_CNNPY:
+            if (t.filters < 1 || t.filters > 16 || t.hidden < 1 || t.hidden > 32 || t.classes < 2 || t.classes > 16) {
+                set_error("cnnpy: need filters 1..16, hidden 1..32, classes 2..16 (got %d,%d,%d)", t.filters, t.hidden, t.classes);
+                return MDC_ENOTSUP;
+            }
+            m->nlayers = 3;
+            m->nk[0] = 2 * 128 * (size_t)t.filters;        m->nb[0] = t.filters;
+            m->nk[1] = 3 * (size_t)t.filters * t.hidden;    m->nb[1] = t.hidden;
+            m->nk[2] = (size_t)t.hidden * t.classes;        m->nb[2] = t.classes;
+            m->slots = {{"mdc_cnnpy_fwd"}};
+            return MDC_OK;
+        default:
+            set_error("unknown topology kind %d", t.kind);
+            return MDC_EINVAL;
+    }
+}
+
+extern "C" {
+
+int mdc_abi_version(void) { return MDC_ABI_VERSION; }
+
+const char* mdc_last_error(void) { return g_err; }
+
+int mdc_create(const mdc_topology* topo, int device, mdc_model** out) {
+    if (!topo || !out) { set_error("mdc_create: null argument"); return MDC_EINVAL; }
+    *out = nullptr;
+    for (int r : topo->reserved) if (r != 0) { set_error("mdc_create: reserved fields must be 0"); return MDC_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MDC_ENODEV; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (have %d)", device, ndev); return MDC_ENODEV; }
+    hipDeviceProp_t prop;
+    MDC_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libmdc.so carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+        return MDC_ENODEV;
+    }
+    mdc_model* m = new (std::nothrow) mdc_model();
+    if (!m) { set_error("out of host memory"); return MDC_ENOMEM; }
+    m->topo = *topo;
+    m->device = device;
+    int rc = layer_layout(m);
+    if (rc != MDC_OK) { delete m; return rc; }
+    *out = m;
+    return MDC_OK;
+}
+
+int mdc_num_layers(const mdc_model* m) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    return m->nlayers;
+}
+
+int mdc_layer_sizes(const mdc_model* m, int layer, size_t* kernel_elems, size_t* bias_elems) {
+    if (!m || layer < 0 || layer >= m->nlayers) { set_error("mdc_layer_sizes: bad layer %d", layer); return MDC_EINVAL; }
+    if (kernel_elems) *kernel_elems = m->nk[layer];
+    if (bias_elems) *bias_elems = m->nb[layer];
+    return MDC_OK;
+}
+
+int mdc_set_weights(mdc_model* m, int layer, const float* kernel_host, size_t kernel_elems,
+                    const float* bias_host, size_t bias_elems) {
+    if (!m || !kernel_host || !bias_host) { set_error("mdc_set_weights: null argument"); return MDC_EINVAL; }
+    if (m->finalized) { set_error("mdc_set_weights: model is finalized (immutable)"); return MDC_ESTATE; }
+    if (layer < 0 || layer >= m->nlayers) { set_error("mdc_set_weights: layer %d out of range 0..%d", layer, m->nlayers - 1); return MDC_EINVAL; }
+    if (kernel_elems != m->nk[layer] || bias_elems != m->nb[layer]) {
+        set_error("mdc_set_weights: layer %d expects kernel %zu / bias %zu elements, got %zu / %zu",
+                  layer, m->nk[layer], m->nb[layer], kernel_elems, bias_elems);
+        return MDC_EINVAL;
+    }
+    m->hk[layer].assign(kernel_host, kernel_host + kernel_elems);
+    m->hb[layer].assign(bias_host, bias_host + bias_elems);
+    m->have[layer] = true;
+    return MDC_OK;
+}
+
+int mdc_finalize(mdc_model* m, int dtype) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    if (m->finalized) { set_error("mdc_finalize: already finalized"); return MDC_ESTATE; }
+    for (int l = 0; l < m->nlayers; ++l)
+        if (!m->have[l]) { set_error("mdc_finalize: layer %d has no weights", l); return MDC_ESTATE; }
+    if (dtype == MDC_FP8) { set_error("fp8 path not implemented yet"); return MDC_ENOTSUP; }
+    if (dtype != MDC_F32 && dtype != MDC_BF16) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
+    if (dtype == MDC_BF16 && m->topo.kind != MDC_KIND_VTCNN2) {
+        set_error("bf16 is implemented for the MFMA-bound vtcnn2 family only; deployed/cnnpy nets are HBM-bound f32");
+        return MDC_ENOTSUP;
+    }
+    m->dtype = dtype;
+    MDC_HIP(hipSetDevice(m->device));
+    int rc;
+    switch (m->topo.kind) {
+        case MDC_KIND_DEPLOYED: rc = deployed_pack(m); break;
+        case MDC_KIND_VTCNN2:   rc = vtcnn2_pack(m); break;
+        case MDC_KIND_CNNPY:    rc = cnnpy_pack(m); break;
+        default: rc = MDC_EINVAL;
+    }
+    if (rc != MDC_OK) return rc;
+    for (int l = 0; l < m->nlayers; ++l) {   // host copies no longer needed
+        std::vector<float>().swap(m->hk[l]);
+        std::vector<float>().swap(m->hb[l]);
+    }
+    m->finalized = true;
+    return MDC_OK;
+}
+
+size_t mdc_workspace_bytes(const mdc_model* m, int64_t n) {
+    if (!m || n <= 0) return 0;
+    if (m->topo.kind == MDC_KIND_VTCNN2) return vtcnn2_workspace_bytes(m, n);
+    return 0;
+}
+
+int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n, float* probs_dev, int32_t* labels_dev,
+                float* tap_dev, int tap, void* workspace_dev, size_t workspace_bytes, void* hip_stream) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    if (!m->finalized) { set_error("mdc_forward: model not finalized"); return MDC_ESTATE; }
+    if (n < 0) { set_error("mdc_forward: negative frame count"); return MDC_EINVAL; }
+    if (n == 0) return MDC_OK;
+    if (!x_dev) { set_error("mdc_forward: null input"); return MDC_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(x_dev) & 15) != 0) { set_error("mdc_forward: input must be 16-byte aligned"); return MDC_EINVAL; }
+    if (tap < MDC_TAP_NONE || tap > MDC_TAP_HIDDEN) { set_error("mdc_forward: bad tap %d", tap); return MDC_EINVAL; }
+    if ((tap != MDC_TAP_NONE) != (tap_dev != nullptr)) { set_error("mdc_forward: tap and tap_dev must be given together"); return MDC_EINVAL; }
+    int cur = -1;
+    MDC_HIP(hipGetDevice(&cur));
+    if (cur != m->device) MDC_HIP(hipSetDevice(m->device));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const float* x = static_cast<const float*>(x_dev);
+    int rc;
+    switch (m->topo.kind) {
+        case MDC_KIND_DEPLOYED: rc = deployed_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, s); break;
+        case MDC_KIND_VTCNN2:   rc = vtcnn2_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, workspace_dev, workspace_bytes, s); break;
+        case MDC_KIND_CNNPY:    rc = cnnpy_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, s); break;
+        default: rc = MDC_EINVAL;
+    }
+    if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
+    return rc;
+}
+
+int mdc_set_profiling(mdc_model* m, int on) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    m->profiling = on != 0;
+    return MDC_OK;
+}
+
+int mdc_profile_slots(const mdc_model* m) { return m ? (int)m->slots.size() : MDC_EINVAL; }
+
+const char* mdc_profile_name(const mdc_model* m, int slot) {
+    if (!m || slot < 0 || slot >= (int)m->slots.size()) return "";
+    return m->slots[slot].name;
+}
+
+int mdc_profile_read(mdc_model* m, int slot, double* total_ms, int64_t* launches) {
+    if (!m || slot < 0 || slot >= (int)m->slots.size()) { set_error("mdc_profile_read: bad slot"); return MDC_EINVAL; }
+    ProfSlot& ps = m->slots[slot];
+    for (size_t i = 0; i + 1 < ps.ev.size(); i += 2) {
+        MDC_HIP(hipEventSynchronize(ps.ev[i + 1]));
+        float ms = 0.f;
+        MDC_HIP(hipEventElapsedTime(&ms, ps.ev[i], ps.ev[i + 1]));
+        ps.total_ms += ms;
+        ps.launches += 1;
+    }
+    for (hipEvent_t e : ps.ev) (void)hipEventDestroy(e);
+    ps.ev.clear();
+    if (total_ms) *total_ms = ps.total_ms;
+    if (launches) *launches = ps.launches;
+    return MDC_OK;
+}
+
+int mdc_profile_reset(mdc_model* m) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    for (ProfSlot& ps : m->slots) {
+        for (hipEvent_t e : ps.ev) (void)hipEventDestroy(e);
+        ps.ev.clear();
+        ps.total_ms = 0;
+        ps.launches = 0;
+    }
+    return MDC_OK;
+}
+
+void mdc_destroy(mdc_model* m) {
+    if (!m) return;
+    for (void*& p : m->d_pack) if (p) { (void)hipFree(p); p = nullptr; }
+    for (ProfSlot& ps : m->slots) for (hipEvent_t e : ps.ev) (void)hipEventDestroy(e);
+    delete m;
+}
+
+}  // extern "C"

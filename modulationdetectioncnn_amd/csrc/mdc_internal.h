@@ -1,0 +1,94 @@
+// Internal declarations shared by the C-ABI shim (mdc_api.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "mdc.h"
+
+namespace mdc {
+
+void set_error(const char* fmt, ...);
+
+#define MDC_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            mdc::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MDC_EIO;                                                                \
+        }                                                                                  \
+    } while (0)
+
+// frame geometry (reference: in_shp = [2, 128], cnn.py:89 / CNN.ipynb cell 5)
+constexpr int kRows = 2;
+constexpr int kSamples = 128;
+constexpr int kFrameFloats = kRows * kSamples;
+
+// canonical VT-CNN2 dimensions (RML2016.10a_VTCNN2_example.ipynb:190-210)
+constexpr int kC1 = 256;     // conv1 filters
+constexpr int kW1 = 130;     // conv1 output width
+constexpr int kC2 = 80;      // conv2 filters
+constexpr int kW2 = 132;     // conv2 output width
+constexpr int kFeat = kC2 * kW2;   // 10560
+constexpr int kHid = 256;    // dense1 units
+
+struct ProfSlot {
+    const char* name;
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    double total_ms = 0;
+    int64_t launches = 0;
+};
+
+}  // namespace mdc
+
+struct mdc_model {
+    mdc_topology topo{};
+    int device = 0;
+    int dtype = MDC_F32;
+    bool finalized = false;
+    int nlayers = 0;
+    size_t nk[4]{}, nb[4]{};
+    std::vector<float> hk[4], hb[4];   // host copies until finalize
+    bool have[4]{};
+
+    // device-resident packed weights (meaning depends on kind/dtype)
+    void* d_pack[8]{};
+    size_t pack_bytes[8]{};
+
+    bool profiling = false;
+    std::vector<mdc::ProfSlot> slots;
+};
+
+namespace mdc {
+
+// RAII-less helper: bracket a launch with events when profiling is on.
+struct ProfScope {
+    mdc_model* m;
+    int slot;
+    hipStream_t s;
+    ProfScope(const mdc_model* mm, int slot_, hipStream_t s_);
+    ~ProfScope();
+};
+
+int upload(mdc_model* m, int idx, const void* host, size_t bytes);
+
+// ---- deployed (T1/T2): deployed.hip -------------------------------------------------
+int deployed_pack(mdc_model* m);
+int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
+                     float* tap, int tap_kind, hipStream_t s);
+
+// ---- cnn.py literal model (T4): cnnpy.hip ----------------------------------------------
+int cnnpy_pack(mdc_model* m);
+int cnnpy_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
+                  float* tap, int tap_kind, hipStream_t s);
+
+// ---- canonical VT-CNN2 (T3): vtcnn2_*.hip ------------------------------------------------
+int vtcnn2_pack(mdc_model* m);
+size_t vtcnn2_workspace_bytes(const mdc_model* m, int64_t n);
+int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
+                   float* tap, int tap_kind, void* ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace mdc

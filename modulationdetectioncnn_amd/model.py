@@ -1,0 +1,295 @@
+"""Host-side mirror of the reference's Keras surface for the inference path.
+
+    reference (cnn.py / CNN.ipynb)                     here
+    -----------------------------------------------    -----------------------------------
+    model = models.Sequential(); model.add(...)        m = VTCNN2(Topology.deployed(3))
+    model.load_weights(filepath)      cnn.py:147       m.load_weights(path)   (.h5 | .txt | .npz)
+    model.predict(X, batch_size=1024) cnn.py:198       m.predict(X, batch_size=1024)
+    int(np.argmax(Y_hat[i,:]))        cnn.py:209       m.predict_classes(X)
+    Model(inputs, layers[i].output)   CNN.ipynb c.17   m.predict(X, tap='conv'|'flat'|'dense')
+
+All arithmetic runs in libmdc.so (hand-written gfx950 HIP) through the C ABI in
+include/mdc.h; PyTorch-ROCm only supplies device memory and the HIP stream.  numpy in ->
+numpy out (PCIe-bound plumbing); torch-ROCm tensor in -> torch tensor out on the same device,
+enqueued on torch's current stream with no synchronisation.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _cabi
+from .formats import q612
+from .formats.h5mini import load_keras_h5
+from .topology import Topology, synthetic_weights
+
+_KIND = {"deployed": _cabi.KIND_DEPLOYED, "vtcnn2": _cabi.KIND_VTCNN2, "cnnpy": _cabi.KIND_CNNPY}
+_DTYPE = {"f32": _cabi.F32, "fp32": _cabi.F32, "float32": _cabi.F32, "bf16": _cabi.BF16, "bfloat16": _cabi.BF16,
+          "fp8": _cabi.FP8}
+_TAP = {None: _cabi.TAP_NONE, "conv": _cabi.TAP_CONV, "flat": _cabi.TAP_FLAT, "dense": _cabi.TAP_DENSE,
+        "hidden": _cabi.TAP_HIDDEN}
+
+Weights = List[Tuple[np.ndarray, np.ndarray]]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class VTCNN2:
+    """A VT-CNN2-family classifier bound to one MI355X."""
+
+    def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32"):
+        self.topology = topology
+        self.dtype = dtype
+        if dtype not in _DTYPE:
+            raise ValueError(f"dtype must be one of {sorted(_DTYPE)}")
+        self._device = device
+        self._weights: Optional[Weights] = None
+        self._handle: Optional[C.c_void_p] = None
+        self._ws = None
+        self.default_chunk = 1 << 16 if topology.kind == "vtcnn2" else 1 << 22
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_h5(cls, path: str, **kw) -> "VTCNN2":
+        ck = load_keras_h5(path)
+        m = cls(Topology.from_keras_config(ck.model_config), **kw)
+        m._set_from_checkpoint(ck)
+        return m
+
+    @classmethod
+    def from_npz(cls, path: str, **kw) -> "VTCNN2":
+        """Decoded-weights fixture (tests/golden/weights/*.npz, made by tools/make_golden.py)."""
+        z = np.load(path)
+        F = int(z["conv_bias"].shape[0])
+        m = cls(Topology.deployed(F, int(z["dense_bias"].shape[0])), **kw)
+        m.set_weights([(z["conv_kernel"], z["conv_bias"]), (z["dense_kernel"], z["dense_bias"])])
+        return m
+
+    @classmethod
+    def from_txt(cls, path: str, conv_from: Optional[str] = None, strict: bool = False, **kw) -> "VTCNN2":
+        """Q6.12 text export.  F=10 dumps hold only the dense kernel: ``conv_from`` names the .h5
+        (or .npz fixture) supplying conv kernel/bias and dense bias."""
+        w = q612.load_weights_txt(path, strict=strict)
+        m = cls(Topology.deployed(w.filters, 3), **kw)
+        donor = None
+        if conv_from is not None:
+            donor = (cls.from_npz(conv_from) if conv_from.endswith(".npz") else cls.from_h5(conv_from))._weights
+        parts = {"conv_kernel": w.conv_kernel, "conv_bias": w.conv_bias, "dense_kernel": w.dense_kernel, "dense_bias": w.dense_bias}
+        if w.placeholder_dense:
+            parts["dense_kernel"] = None      # 12.14.weights.txt: six identical placeholder tables
+        if donor is not None:
+            fill = {"conv_kernel": donor[0][0], "conv_bias": donor[0][1], "dense_kernel": donor[1][0], "dense_bias": donor[1][1]}
+            for k, v in fill.items():
+                if parts[k] is None:
+                    parts[k] = v
+        missing = [k for k, v in parts.items() if v is None]
+        if missing:
+            raise ValueError(f"{os.path.basename(path)} lacks {missing}; pass conv_from=<.h5 or .npz>")
+        m.set_weights([(parts["conv_kernel"], parts["conv_bias"]), (parts["dense_kernel"], parts["dense_bias"])])
+        return m
+
+    @classmethod
+    def synthetic(cls, topology: Union[Topology, str] = "vtcnn2", classes: int = 11, seed: int = 2016,
+                  bias_scale: float = 0.0, **kw) -> "VTCNN2":
+        if isinstance(topology, str):
+            topology = {"vtcnn2": Topology.vtcnn2(classes), "deployed3": Topology.deployed(3, 3),
+                        "deployed10": Topology.deployed(10, 3), "cnnpy": Topology.cnnpy(10, 10, classes)}[topology]
+        m = cls(topology, **kw)
+        m.set_weights(synthetic_weights(topology, seed, bias_scale))
+        return m
+
+    # ------------------------------------------------------------------ weights
+    def _set_from_checkpoint(self, ck) -> None:
+        tensors = [a for l in ck.layer_names for _, a in ck.weights[l]]
+        if len(tensors) != 2 * len(self.topology.layer_shapes):
+            raise ValueError(f"{ck.path}: {len(tensors)} tensors for {len(self.topology.layer_shapes)} weighted layers")
+        self.set_weights([(tensors[2 * i], tensors[2 * i + 1]) for i in range(len(tensors) // 2)])
+
+    def load_weights(self, filepath: str, conv_from: Optional[str] = None) -> None:
+        """``model.load_weights(filepath)`` (cnn.py:147): topology must match the file's."""
+        if filepath.endswith((".h5", ".hdf5")):
+            ck = load_keras_h5(filepath)
+            t = Topology.from_keras_config(ck.model_config)
+            if t != self.topology:
+                raise ValueError(f"{filepath} holds {t}, model is {self.topology}")
+            self._set_from_checkpoint(ck)
+        elif filepath.endswith(".npz"):
+            self.set_weights(VTCNN2.from_npz(filepath)._weights)
+        elif filepath.endswith(".txt"):
+            self.set_weights(VTCNN2.from_txt(filepath, conv_from=conv_from)._weights)
+        else:
+            raise ValueError(f"unknown weight file type: {filepath}")
+
+    def set_weights(self, weights: Sequence[Tuple[np.ndarray, np.ndarray]]) -> None:
+        shapes = self.topology.layer_shapes
+        if len(weights) != len(shapes):
+            raise ValueError(f"expected {len(shapes)} (kernel, bias) pairs, got {len(weights)}")
+        out = []
+        for i, ((k, b), (ks, bs)) in enumerate(zip(weights, shapes)):
+            k = np.ascontiguousarray(k, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            if tuple(k.shape) != ks or tuple(b.shape) != bs:
+                raise ValueError(f"layer {i} ({self.topology.layer_names[i]}): expected kernel {ks} bias {bs}, got {k.shape} {b.shape}")
+            out.append((k, b))
+        self._weights = out
+        self._release()
+
+    def get_weights(self) -> Weights:
+        if self._weights is None:
+            raise RuntimeError("no weights loaded")
+        return [(k.copy(), b.copy()) for k, b in self._weights]
+
+    # ------------------------------------------------------------------ engine
+    @property
+    def device_index(self) -> int:
+        torch = _torch()
+        d = self._device
+        if d is None:
+            return torch.cuda.current_device()
+        if isinstance(d, int):
+            return d
+        return torch.device(d).index or 0
+
+    def _engine(self) -> C.c_void_p:
+        if self._handle is not None:
+            return self._handle
+        if self._weights is None:
+            raise RuntimeError("load_weights() before predict()")
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device visible: the MI355X path has no CPU fallback")
+        L = _cabi.lib()
+        t = self.topology
+        topo = _cabi.MdcTopology(_KIND[t.kind], t.filters, t.hidden, t.classes, (C.c_int32 * 4)(0, 0, 0, 0))
+        h = C.c_void_p()
+        _cabi.check(L.mdc_create(C.byref(topo), self.device_index, C.byref(h)))
+        try:
+            for i, (k, b) in enumerate(self._weights):
+                _cabi.check(L.mdc_set_weights(h, i, k.ctypes.data_as(C.POINTER(C.c_float)), k.size,
+                                              b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
+            _cabi.check(L.mdc_finalize(h, _DTYPE[self.dtype]))
+        except Exception:
+            L.mdc_destroy(h)
+            raise
+        self._handle = h
+        return h
+
+    def _release(self) -> None:
+        if self._handle is not None:
+            _cabi.lib().mdc_destroy(self._handle)
+            self._handle = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _workspace(self, n: int):
+        L = _cabi.lib()
+        need = int(L.mdc_workspace_bytes(self._engine(), n))
+        if need == 0:
+            return None, 0
+        torch = _torch()
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=f"cuda:{self.device_index}")
+        return self._ws, need
+
+    # ------------------------------------------------------------------ inference
+    def tap_shape(self, tap: str) -> Tuple[int, ...]:
+        t = self.topology
+        if t.kind == "deployed":
+            return {"conv": (2, 129, t.filters), "flat": (258 * t.filters,), "dense": (t.classes,)}[tap]
+        if t.kind == "vtcnn2":
+            return {"conv": (80, 132), "flat": (10560,), "dense": (t.classes,), "hidden": (256,)}[tap]
+        return {"conv": (1, 3, t.filters), "flat": (3 * t.filters,), "dense": (t.classes,), "hidden": (t.hidden,)}[tap]
+
+    def forward_device(self, x, probs=None, labels=None, tap: Optional[str] = None, tap_out=None,
+                       batch_size: Optional[int] = None):
+        """Enqueue the forward on torch's current stream.  x: contiguous float32 CUDA tensor (n,2,128).
+        Pre-allocated outputs may be passed; returns (probs, labels, tap_out)."""
+        torch = _torch()
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise TypeError("forward_device needs a torch tensor on the ROCm device")
+        if x.dtype != torch.float32 or tuple(x.shape[1:]) != (2, 128) or not x.is_contiguous():
+            raise ValueError(f"input must be contiguous float32 (n,2,128); got {x.dtype} {tuple(x.shape)}")
+        if x.device.index != self.device_index:
+            raise ValueError(f"input on cuda:{x.device.index}, model on cuda:{self.device_index}")
+        if tap not in _TAP:
+            raise ValueError(f"tap must be one of {[k for k in _TAP if k]}")
+        n = x.shape[0]
+        Cn = self.topology.classes
+        h = self._engine()
+        L = _cabi.lib()
+        dev = x.device
+        if probs is None:
+            probs = torch.empty((n, Cn), dtype=torch.float32, device=dev)
+        if labels is None:
+            labels = torch.empty((n,), dtype=torch.int32, device=dev)
+        if tap is not None and tap_out is None:
+            tap_out = torch.empty((n,) + self.tap_shape(tap), dtype=torch.float32, device=dev)
+        if n == 0:
+            return probs, labels, tap_out
+        chunk = int(batch_size) if batch_size else self.default_chunk
+        chunk = max(1, min(chunk, n))
+        ws, ws_bytes = self._workspace(chunk)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        tap_row = int(np.prod(self.tap_shape(tap))) if tap is not None else 0
+        for s in range(0, n, chunk):
+            m = min(chunk, n - s)
+            _cabi.check(L.mdc_forward(
+                h, x.data_ptr() + s * 1024, m,
+                probs.data_ptr() + s * Cn * 4, labels.data_ptr() + s * 4,
+                (tap_out.data_ptr() + s * tap_row * 4) if tap is not None else None, _TAP[tap],
+                ws.data_ptr() if ws is not None else None, ws_bytes, stream))
+        return probs, labels, tap_out
+
+    def _run(self, X, batch_size, tap):
+        torch = _torch()
+        as_numpy = not isinstance(X, torch.Tensor)
+        if as_numpy:
+            a = np.ascontiguousarray(np.asarray(X), dtype=np.float32)
+            if a.ndim != 3 or a.shape[1:] != (2, 128):
+                raise ValueError(f"expected input of shape (n,2,128); got {a.shape}")
+            x = torch.from_numpy(a).to(f"cuda:{self.device_index}")
+        else:
+            x = X
+            if not x.is_cuda:
+                x = x.to(f"cuda:{self.device_index}")
+            x = x.to(torch.float32).contiguous()
+        probs, labels, tap_out = self.forward_device(x, tap=tap, batch_size=batch_size)
+        return as_numpy, probs, labels, tap_out
+
+    def predict(self, X, batch_size: Optional[int] = None, tap: Optional[str] = None):
+        """``model.predict(X, batch_size)``: (n,C) float32 softmax rows; with ``tap`` the named
+        intermediate layer of CNN.ipynb cell 17 instead.  Results do not depend on batch_size."""
+        as_numpy, probs, _labels, tap_out = self._run(X, batch_size, tap)
+        out = tap_out if tap is not None else probs
+        return out.cpu().numpy() if as_numpy else out
+
+    def predict_classes(self, X, batch_size: Optional[int] = None):
+        """Row-wise ``np.argmax`` of predict(X) (cnn.py:209: first maximum wins), int32 (n,)."""
+        as_numpy, _probs, labels, _ = self._run(X, batch_size, None)
+        return labels.cpu().numpy() if as_numpy else labels
+
+    # ------------------------------------------------------------------ measurement hooks
+    def set_profiling(self, on: bool) -> None:
+        _cabi.check(_cabi.lib().mdc_set_profiling(self._engine(), int(on)))
+        if on:
+            _cabi.check(_cabi.lib().mdc_profile_reset(self._engine()))
+
+    def read_profile(self) -> Dict[str, Tuple[float, int]]:
+        L, h = _cabi.lib(), self._engine()
+        out = {}
+        for i in range(L.mdc_profile_slots(h)):
+            ms, cnt = C.c_double(), C.c_int64()
+            _cabi.check(L.mdc_profile_read(h, i, C.byref(ms), C.byref(cnt)))
+            out[L.mdc_profile_name(h, i).decode()] = (ms.value, cnt.value)
+        return out

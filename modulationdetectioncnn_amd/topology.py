@@ -1,0 +1,147 @@
+"""Topologies of the VT-CNN2 family and their weights in the reference's (Keras) layouts.
+
+Three families:
+  deployed  CNN.ipynb cell 6 / model_config of the bundled .h5 (T1: F=3, T2: F=10)
+  vtcnn2    examples-master/.../RML2016.10a_VTCNN2_example.ipynb:229-243 (T3, canonical)
+  cnnpy     cnn.py:104-115 as TensorFlow actually builds it (T4: H=1, W=2, C=128)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+CLASSES_3 = ["WBFM", "AM-SSB", "GFSK"]                 # CNN.ipynb cell 2 (index order of one-hot)
+CLASSES_5 = ["BPSK", "GFSK", "QAM16", "QPSK", "WBFM"]  # cnn.py:47
+CLASSES_11 = ["8PSK", "AM-DSB", "AM-SSB", "BPSK", "CPFSK", "GFSK", "PAM4", "QAM16", "QAM64", "QPSK", "WBFM"]  # CNN.ipynb cell 3
+
+
+@dataclass(frozen=True)
+class Topology:
+    kind: str          # 'deployed' | 'vtcnn2' | 'cnnpy'
+    filters: int
+    hidden: int
+    classes: int
+
+    # -- constructors -------------------------------------------------------
+    @staticmethod
+    def deployed(filters: int = 3, classes: int = 3) -> "Topology":
+        return Topology("deployed", int(filters), 0, int(classes))
+
+    @staticmethod
+    def vtcnn2(classes: int = 11) -> "Topology":
+        return Topology("vtcnn2", 256, 256, int(classes))
+
+    @staticmethod
+    def cnnpy(filters: int = 10, hidden: int = 10, classes: int = 5) -> "Topology":
+        return Topology("cnnpy", int(filters), int(hidden), int(classes))
+
+    @staticmethod
+    def from_keras_config(cfg: dict) -> "Topology":
+        """Recognise a Keras ``model_config`` (the JSON attribute inside a .h5)."""
+        layers = [(l["class_name"], l["config"]) for l in cfg["config"]["layers"] if l["class_name"] != "InputLayer"]
+        names = [n for n, _ in layers]
+        convs = [c for n, c in layers if n == "Conv2D"]
+        denses = [c for n, c in layers if n == "Dense"]
+        reshape = next((c for n, c in layers if n == "Reshape"), None)
+        if not convs or not denses or reshape is None:
+            raise ValueError(f"not a VT-CNN2-family model: layers {names}")
+        tgt = list(reshape.get("target_shape", []))
+        if tgt == [2, 128, 1] and len(convs) == 1 and len(denses) == 1 and list(convs[0]["kernel_size"]) == [1, 2]:
+            if denses[0].get("activation") != "relu":
+                raise ValueError("deployed net: Dense activation must be relu")
+            return Topology.deployed(convs[0]["filters"], denses[0]["units"])
+        if tgt == [1, 2, 128] and len(convs) == 1 and len(denses) == 2 and list(convs[0]["kernel_size"]) == [1, 2]:
+            return Topology.cnnpy(convs[0]["filters"], denses[0]["units"], denses[1]["units"])
+        if len(convs) == 2 and len(denses) == 2 and convs[0]["filters"] == 256 and convs[1]["filters"] == 80:
+            return Topology.vtcnn2(denses[1]["units"])
+        raise ValueError(f"unsupported topology: reshape {tgt}, convs {[c['filters'] for c in convs]}, denses {[d['units'] for d in denses]}")
+
+    # -- shapes -------------------------------------------------------------
+    @property
+    def layer_names(self) -> List[str]:
+        return {"deployed": ["conv", "dense"], "vtcnn2": ["conv1", "conv2", "dense1", "dense2"],
+                "cnnpy": ["conv", "dense1", "dense2"]}[self.kind]
+
+    @property
+    def layer_shapes(self) -> List[Tuple[Tuple[int, ...], Tuple[int, ...]]]:
+        """[(kernel_shape, bias_shape)] in the layout ``load_weights`` delivers."""
+        F, D, C = self.filters, self.hidden, self.classes
+        if self.kind == "deployed":
+            return [((1, 2, 1, F), (F,)), ((258 * F, C), (C,))]                  # HWIO; (in,out)
+        if self.kind == "vtcnn2":
+            return [((256, 1, 1, 3), (256,)), ((80, 256, 2, 3), (80,)),             # OIHW (Keras-1 'th')
+                    ((10560, 256), (256,)), ((256, C), (C,))]
+        if self.kind == "cnnpy":
+            return [((1, 2, 128, F), (F,)), ((3 * F, D), (D,)), ((D, C), (C,))]
+        raise ValueError(self.kind)
+
+    @property
+    def flatten_order(self) -> str:
+        return "channels_first" if self.kind == "vtcnn2" else "channels_last"
+
+    @property
+    def flops_per_frame(self) -> int:
+        """2 FLOP per MAC; bias/ReLU/softmax ignored; padding MACs included."""
+        F, D, C = self.filters, self.hidden, self.classes
+        if self.kind == "deployed":
+            return 2 * (258 * F * 2 + 258 * F * C)
+        if self.kind == "vtcnn2":
+            return 2 * (256 * 2 * 130 * 3 + 80 * 132 * 256 * 6 + 10560 * 256 + 256 * C)
+        return 2 * (3 * F * 256 + 3 * F * D + D * C)
+
+    @property
+    def conv_flops_per_frame(self) -> int:
+        if self.kind != "vtcnn2":
+            raise ValueError("conv-only count is defined for vtcnn2")
+        return 2 * (256 * 2 * 130 * 3 + 80 * 132 * 256 * 6)
+
+    @property
+    def io_bytes_per_frame(self) -> int:
+        """Algorithmic HBM bytes: f32 frame in + f32 probabilities out."""
+        return 2 * 128 * 4 + 4 * self.classes
+
+    def class_names(self) -> List[str]:
+        return {3: CLASSES_3, 5: CLASSES_5, 11: CLASSES_11}.get(self.classes, [str(i) for i in range(self.classes)])
+
+
+def glorot_uniform(rng: np.random.Generator, shape: Sequence[int], fan_in: int, fan_out: int) -> np.ndarray:
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def he_normal(rng: np.random.Generator, shape: Sequence[int], fan_in: int) -> np.ndarray:
+    return (rng.standard_normal(size=shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+
+
+def synthetic_weights(topo: Topology, seed: int = 2016, bias_scale: float = 0.0) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Random-init weights with the reference's initialisers: glorot_uniform convs, he_normal
+    denses, zero biases (cnn.py:108-111; RML2016.10a_VTCNN2_example.ipynb:233-241).
+    ``bias_scale`` > 0 draws N(0, bias_scale) biases instead, so tests exercise the bias paths."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for (ks, bs) in topo.layer_shapes:
+        if len(ks) == 4:
+            if topo.kind == "vtcnn2":       # OIHW
+                o, i, kh, kw = ks
+            else:                           # HWIO
+                kh, kw, i, o = ks
+            k = glorot_uniform(rng, ks, i * kh * kw, o * kh * kw)
+        else:
+            k = he_normal(rng, ks, ks[0])
+        b = (rng.standard_normal(bs) * bias_scale).astype(np.float32) if bias_scale > 0 else np.zeros(bs, np.float32)
+        out.append((k, b))
+    return out
+
+
+def synthetic_frames(n: int, seed: int = 2016, sigma: float = 5e-3, device=None):
+    """X ~ N(0, sigma) float32 (n,2,128): the bundled frames' scale.
+    numpy on host, or a torch tensor generated directly on `device`."""
+    if device is None:
+        rng = np.random.default_rng(seed)
+        return (rng.standard_normal((n, 2, 128)) * sigma).astype(np.float32)
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.randn((n, 2, 128), generator=g, device=device, dtype=torch.float32) * sigma

@@ -1,0 +1,160 @@
+"""Parity of the HIP deployed-net path (T1 F=3, T2 F=10) against the CPU oracle, through the C ABI.
+
+Tolerances: Dense+ReLU tap 5e-6 abs for the Keras known answer;
+2e-6 * scale abs for f32 vs the f64 oracle elsewhere; probabilities 2e-6 abs.  Labels must be
+bit-exact wherever the f64 oracle's top-2 margin exceeds 1e-5 (relative to the largest
+output); exact ties ([0,0,0] after ReLU) must resolve to the FIRST maximum."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, H5_NAMES, load_deployed_npz
+from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames, synthetic_weights
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames():
+    raw = np.load(os.path.join(GOLDEN, "frames.npz"))["raw"]
+    meta = json.load(open(os.path.join(GOLDEN, "frames.json")))
+    return raw.astype(np.float32) / np.float32(4096), meta
+
+
+def _model(name):
+    return VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"))
+
+
+def _check_labels(lab, ref64, tol=1e-5):
+    d = ref64["dense"]
+    srt = np.sort(d, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    scale = np.maximum(np.abs(d).max(axis=1), 1e-30)
+    decided = margin > tol * scale
+    exact_tie = margin == 0
+    assert (lab[decided] == ref64["labels"][decided]).all()
+    assert (lab[exact_tie] == ref64["labels"][exact_tie]).all()      # first-max on exact ties
+    return int((~decided & ~exact_tie).sum())
+
+
+def test_keras_known_answer_on_gpu():
+    k = json.load(open(os.path.join(GOLDEN, "keras_kat.json")))
+    x = np.asarray(k["input"], np.float32).reshape(1, 2, 128)
+    m = _model("3convmodrecnets_CNN2_0.5")
+    dense = m.predict(x, tap="dense")
+    assert np.abs(dense[0] - np.array(k["keras_dense"])).max() < 5e-6
+    assert m.predict_classes(x).tolist() == [0]
+    np.testing.assert_allclose(m.predict(x)[0], [0.67148, 0.24728, 0.08124], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", H5_NAMES)
+def test_bundled_frames_all_checkpoints(name):
+    x, meta = _frames()
+    fz = json.load(open(os.path.join(GOLDEN, "oracle_frozen.json")))["by_weights"][name]
+    m = _model(name)
+    dense = m.predict(x, tap="dense")
+    np.testing.assert_allclose(dense, np.array(fz["dense"]), rtol=0, atol=5e-6)
+    assert m.predict_classes(x).tolist() == fz["labels"]
+    w = [a for p in load_deployed_npz(name) for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)
+    np.testing.assert_allclose(m.predict(x), ref["probs"], atol=2e-6)
+    if name.startswith("3conv"):
+        i0 = meta["names"].index("12.16.testDataYunyun.txt#0")
+        assert np.abs(dense[i0] - np.array([0.0, 3.1391976, 0.3649335])).max() < 5e-3
+
+
+@pytest.mark.parametrize("name", ["3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 65536])
+def test_synthetic_parity(name, n):
+    x = synthetic_frames(n, seed=2016)
+    w = [a for p in load_deployed_npz(name) for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)
+    m = _model(name)
+    scale = max(1.0, float(np.abs(ref["dense"]).max()))
+    np.testing.assert_allclose(m.predict(x, tap="dense"), ref["dense"], rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(m.predict(x), ref["probs"], rtol=0, atol=2e-6)
+    undecided = _check_labels(m.predict_classes(x), ref)
+    assert undecided <= max(1, n // 20000)
+
+
+@pytest.mark.parametrize("filters", [3, 10])
+def test_taps_conv_and_flat(filters):
+    topo = Topology.deployed(filters)
+    w = synthetic_weights(topo, seed=11, bias_scale=0.01)
+    x = synthetic_frames(130, seed=5, sigma=0.05)
+    ref = O.forward("deployed", x, w, dtype=np.float64)
+    m = VTCNN2(topo)
+    m.set_weights(w)
+    conv = m.predict(x, tap="conv")
+    assert conv.shape == (130, 2, 129, filters)
+    np.testing.assert_allclose(conv, ref["conv"], rtol=0, atol=1e-6)
+    flat = m.predict(x, tap="flat")
+    np.testing.assert_array_equal(flat, conv.reshape(130, -1))
+    np.testing.assert_allclose(m.predict(x, tap="dense"), ref["dense"], rtol=0, atol=2e-6 * max(1.0, np.abs(ref["dense"]).max()))
+
+
+def test_batch_size_invariance_and_torch_io():
+    m = _model("3convmodrecnets_CNN2_0.5")
+    x = synthetic_frames(5000, seed=3, device="cuda")
+    a = m.predict(x)
+    assert isinstance(a, torch.Tensor) and a.is_cuda and a.shape == (5000, 3)
+    for bs in (1, 7, 64, 1024, 4999):
+        if bs == 1:
+            b = m.predict(x[:300], batch_size=1)
+            assert torch.equal(a[:300], b)
+        else:
+            assert torch.equal(a, m.predict(x, batch_size=bs))
+    assert torch.equal(m.predict_classes(x).cpu(), torch.from_numpy(m.predict_classes(x.cpu().numpy())))
+
+
+def test_first_max_tie_break_and_relu_zero():
+    # all-zero input under 5conv: Dense pre-activations are the biases; force exact ties by weights
+    topo = Topology.deployed(3)
+    w = synthetic_weights(topo, seed=1)
+    (ck, cb), (dk, db) = w
+    dk[:] = -np.abs(dk)                      # all-negative dense kernel -> z = relu(negative) = 0 exactly
+    cb[:] = 0.5
+    db[:] = 0.0
+    m = VTCNN2(topo)
+    m.set_weights([(ck, cb), (dk, db)])
+    x = synthetic_frames(257, seed=9)
+    assert (m.predict(x, tap="dense") == 0).all()
+    assert (m.predict_classes(x) == 0).all()
+    np.testing.assert_array_equal(m.predict(x), np.full((257, 3), np.float32(1 / 3)))
+    # two-way tie between classes 1 and 2, class 0 lower -> label 1
+    db[:] = [0.0, 1.0, 1.0]
+    m.set_weights([(ck, cb), (dk, db)])
+    assert (m.predict_classes(x) == 1).all()
+
+
+def test_empty_and_errors():
+    m = _model("3convmodrecnets_CNN2_0.5")
+    assert m.predict(np.zeros((0, 2, 128), np.float32)).shape == (0, 3)
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((4, 2, 127), np.float32))
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((1, 2, 128), np.float32), tap="nonsense")
+    with pytest.raises(ValueError):
+        VTCNN2(Topology.deployed(3)).set_weights(load_deployed_npz("convmodrecnets_CNN2_0.5"))
+    from modulationdetectioncnn_amd._cabi import MdcError
+    with pytest.raises(MdcError):
+        VTCNN2.from_npz(os.path.join(GOLDEN, "weights", "3convmodrecnets_CNN2_0.5.npz"), dtype="bf16").predict(np.zeros((1, 2, 128), np.float32))
+
+
+def test_txt_weights_load_and_classify(tmp_path):
+    """Q6.12 text export -> same labels as the .h5 weights on the bundled frames (weights differ by < 1 LSB)."""
+    from modulationdetectioncnn_amd.formats import q612
+    z = np.load(os.path.join(GOLDEN, "weights_txt", "12.15.latestWeights.npz"))
+    m = VTCNN2(Topology.deployed(3))
+    m.set_weights([(z["conv_kernel"], z["conv_bias"]), (z["dense_kernel"], z["dense_bias"])])
+    x, _ = _frames()
+    fz = json.load(open(os.path.join(GOLDEN, "oracle_frozen.json")))["by_weights"]["3convmodrecnets_CNN2_0.5"]
+    assert m.predict_classes(x).tolist() == fz["labels"]
+    w = q612.DeployedWeights(3, z["conv_kernel"], z["conv_bias"], z["dense_kernel"], z["dense_bias"])
+    p = tmp_path / "w.txt"
+    p.write_text(q612.dump_weights_f3(w))
+    m2 = VTCNN2.from_txt(str(p))
+    assert m2.predict_classes(x).tolist() == fz["labels"]

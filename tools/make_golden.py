@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the reference's DATA files (run in the build container).
+
+Reads (never executes) under /root/reference:
+  * the five Keras .h5 checkpoints            -> golden/weights/<name>.npz   (decoded f32 tensors)
+  * the fifteen Q6.12 frame .txt files         -> golden/frames.npz + frames.json
+  * the seven Q6.12 weight .txt files          -> golden/weights_txt/<name>.npz
+  * CNN.ipynb cell 18 stored output (text)     -> golden/keras_kat.json  (float input + Keras answer)
+  * the "* prediction:" comments of 12.16.testDataYunyun.txt -> frames.json
+
+Everything written is derived data (arrays / numbers); no reference source text is copied.
+Oracle-derived expectations (labels frozen per SURVEY.md 8(c)(5)) are written by
+tools/freeze_oracle_labels.py AFTER the oracle passes the Keras known answers.
+"""
+import glob
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from modulationdetectioncnn_amd.formats import q612            # noqa: E402
+from modulationdetectioncnn_amd.formats.h5mini import load_keras_h5   # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+FRAME_FILES = [
+    "12.14.testdata.class2.txt", "12.14.testdata.class3.txt", "12.15.newTestFirst.txt",
+    "12.15.newTestSecond.txt", "12.15.newTestThird.txt", "12.15.newTestFourth.txt",
+    "12.15.sixSampleData.txt", "12.15.sixtyfourSamples.txt", "12.15.testDataClass1.txt",
+    "12.15testDataClass2.txt", "12.15.testDataClass3.txt", "12.16.testDataYunyun.txt",
+    "newTestData.txt", "newTestDataClass2.txt", "newTestDataClass3.txt",
+]
+WEIGHT_TXT = ["12.14.weights.txt", "12.15.denseWeights.txt", "12.15.latestWeights.txt",
+              "am.fm.8psk.txt", "am.fm.qpsk.txt", "DenseWeights1.txt", "newDenseWeights.txt"]
+
+
+def cell18():
+    nb = json.load(open(os.path.join(REF, "CNN.ipynb")))
+    cell = nb["cells"][18]
+    text = "".join("".join(o.get("text", "")) for o in cell["outputs"])
+    # the printed (1,2,128) array, then the 3-vector on the last line
+    head, tail = text.rsplit("]]]", 1)
+    nums = [float(t) for t in re.findall(r"-?\d+\.\d*(?:e[-+]?\d+)?|-?\d+\.", head)]
+    assert len(nums) == 256, len(nums)
+    pred = [float(t) for t in re.findall(r"-?\d+\.\d+", tail)]
+    assert len(pred) == 3, pred
+    return np.asarray(nums, np.float32).reshape(1, 2, 128), pred, cell.get("execution_count")
+
+
+def main():
+    os.makedirs(os.path.join(OUT, "weights"), exist_ok=True)
+    os.makedirs(os.path.join(OUT, "weights_txt"), exist_ok=True)
+    manifest = {"h5": {}, "txt": {}}
+    for p in sorted(glob.glob(os.path.join(REF, "*.h5"))):
+        ck = load_keras_h5(p)
+        name = os.path.basename(p).replace(".wts.h5", "")
+        arrs = {}
+        tensors = [a for l in ck.layer_names for _, a in ck.weights[l]]
+        assert len(tensors) == 4
+        arrs = dict(conv_kernel=tensors[0], conv_bias=tensors[1], dense_kernel=tensors[2], dense_bias=tensors[3])
+        np.savez(os.path.join(OUT, "weights", name + ".npz"), **arrs)
+        layers = [(l["class_name"], {k: l["config"].get(k) for k in
+                                     ("target_shape", "padding", "filters", "kernel_size", "units", "activation", "data_format")
+                                     if k in l["config"]}) for l in ck.layer_configs()]
+        manifest["h5"][name] = {"keras_version": ck.keras_version, "backend": ck.backend,
+                                "layer_names": ck.layer_names, "layers": layers,
+                                "shapes": {k: list(v.shape) for k, v in arrs.items()},
+                                "bytes": os.path.getsize(p)}
+    for t in WEIGHT_TXT:
+        w = q612.load_weights_txt(os.path.join(REF, t))
+        arrs = {k: getattr(w, k) for k in ("conv_kernel", "conv_bias", "dense_kernel", "dense_bias") if getattr(w, k) is not None}
+        np.savez(os.path.join(OUT, "weights_txt", t[:-4] + ".npz"), **arrs)
+        manifest["txt"][t] = {"filters": w.filters, "parts": sorted(arrs), "negzero": w.negzero,
+                              "placeholder_dense": w.placeholder_dense}
+
+    names, raws, nzs, preds = [], [], [], []
+    for fn in FRAME_FILES:
+        ff = q612.load_frames(os.path.join(REF, fn))
+        strict = q612.load_frames(os.path.join(REF, fn), strict=True)
+        for i in range(ff.raw.shape[0]):
+            names.append(fn if ff.raw.shape[0] == 1 else f"{fn}#{i}")
+            raws.append(ff.raw[i])
+            nzs.append(ff.negzero[i])
+            preds.append(ff.predictions[i])
+            assert (strict.raw[i].ravel()[ff.negzero[i]] < 0).all()
+    np.savez(os.path.join(OUT, "frames.npz"), raw=np.stack(raws).astype(np.int32))
+    json.dump({"names": names, "negzero_rows": nzs, "keras_prediction": preds,
+               "note": "raw = Q6.12 integers after negative-zero repair; value = raw/4096"},
+              open(os.path.join(OUT, "frames.json"), "w"), indent=1)
+
+    x, pred, exe = cell18()
+    json.dump({"source": "CNN.ipynb cell 18 stored output (execution_count %s)" % exe,
+               "weights": "3convmodrecnets_CNN2_0.5", "tap": "dense (model2 = layers[4].output, post-ReLU, pre-softmax)",
+               "input": [float(np.float32(v)) for v in x.ravel()], "keras_dense": pred},
+              open(os.path.join(OUT, "keras_kat.json"), "w"))
+    json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()
