@@ -1,7 +1,428 @@
-// placeholder (filled in below in this round): canonical VT-CNN2 (T3)
+// Canonical VT-CNN2 (T3): host-side packing, f32 kernels, the softmax head and the
+// per-call dispatcher.  The bf16 kernels live in vtcnn2_bf16.hip.
+//
+// Math restated from examples-master/.../RML2016.10a_VTCNN2_example.ipynb:229-243
+// (shapes :190-210), SURVEY.md 8(a) A2:
+//   xp   = pad2(x)                                  (2,132)
+//   y1   = relu(b1[c] + sum_t K1[c,t] xp[h,v+t])    (256,2,130)   v = 0..129
+//   y1p  = pad2(y1)                                 (256,2,134)
+//   y2   = relu(b2[o] + sum_{c,h,j} K2[o,c,h,j] y1p[c,h,w+j])   (80,132)   w = 0..131
+//   hid  = relu(W1^T flat(y2) + c1)                 (256)         flat index o*132 + w
+//   p    = softmax(W2^T hid + c2)                   (C)
+//
+// "Lane = frame" mapping shared by both dtypes: an MFMA's 16-wide N dimension is 16
+// FRAMES at one time position.  A conv1 MFMA then yields X[channel][frame] for one padded
+// position w'; in the 16x16 C/D layout a lane holds channels 4g..4g+3 of its frame, which is
+// exactly a B operand of the next MFMA (k = channel), so conv1's output feeds conv2 from
+// registers with no LDS round trip and no im2col buffer.  The three conv2 taps of one X are
+// three MFMAs into the accumulators of output positions w', w'-1, w'-2: the tap shift is a
+// choice of accumulator register, never a data movement.  Zero padding of y1p is free
+// (those positions are simply skipped).
+//
+// Intermediate layout in HBM (workspace): feat[frame][w][o]  (o fastest, 80 per position).
+// dense1's weight rows are permuted to that order at pack time, so the reference's
+// channels_first Flatten is never materialised (only the 'flat'/'conv' taps un-permute).
 #include "mdc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
 namespace mdc {
-int vtcnn2_pack(mdc_model*) { set_error("vtcnn2 kernels not built yet"); return MDC_ENOTSUP; }
-size_t vtcnn2_workspace_bytes(const mdc_model*, int64_t) { return 0; }
-int vtcnn2_forward(const mdc_model*, const float*, int64_t, float*, int32_t*, float*, int, void*, size_t, hipStream_t) { set_error("vtcnn2 kernels not built yet"); return MDC_ENOTSUP; }
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+namespace {
+
+// async global -> LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+// ------------------------------------------------------------------------------------
+// f32 conv1+conv2: v_mfma_f32_16x16x4_f32 (exact f32 fma chains).
+// Workgroup = 4 waves, each wave owns 16 frames (no cross-wave reduction).  Loop nest:
+// position block (11 outputs) x 16-channel chunk (conv2 weights of the chunk, 30 KB, staged
+// in LDS and shared by the 4 waves) x 13 padded positions x 2 rows x [1 conv1 + 60 conv2 MFMAs].
+// ------------------------------------------------------------------------------------
+constexpr int kP = 11;                 // output positions per block
+constexpr int kNPB = kW2 / kP;         // 12 blocks
+constexpr int kChunk = 16;             // channels per chunk
+constexpr int kNChunk = kC1 / kChunk;  // 16
+constexpr int kWChunkFloats = 2 * 3 * 5 * 4 * 64;   // [h][j][ot][r][lane] = 7680
+constexpr int kXld = 133;              // LDS row stride of a padded input row (132 + 1)
+constexpr int kXinFloats = 4 * 2 * 16 * kXld;
+constexpr size_t kConvF32Lds = (2 * kWChunkFloats + kXinFloats) * sizeof(float);
+
+__global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __restrict__ x, long n,
+                                                             const float* __restrict__ wpack,   // [16 chunks][7680]
+                                                             const float* __restrict__ a1pack,  // [16 chunks][64 lanes]
+                                                             const float* __restrict__ b2,      // [80]
+                                                             float* __restrict__ feat) {        // [n][132][80]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wbuf = smem;
+    float* xin = smem + 2 * kWChunkFloats;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const int nl = lane & 15, g = lane >> 4;
+    const long frame0 = (long)blockIdx.x * 64 + q * 16;
+
+    // ---- stage this wave's 16 frames, zero-padded by 2 on both sides of each row ----
+    float* xw = xin + q * (2 * 16 * kXld);
+    {
+        const int h = lane >> 5, s = (lane & 31) * 4;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const long f = frame0 + i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < n) v = reinterpret_cast<const float4*>(x + f * kFrameFloats)[lane];
+            float* d = xw + (h * 16 + i) * kXld + 2 + s;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        for (int r = lane; r < 32 * 5; r += 64) {
+            const int row = r / 5, k = r % 5;
+            xw[row * kXld + (k < 2 ? k : 128 + k)] = 0.f;     // 0,1,130,131,132
+        }
+    }
+    // ---- chunk 0 of the conv2 weights: LDS-DMA, 30 pieces of 1 KiB, piece p by wave p%4 ----
+    for (int p = q; p < kWChunkFloats / 256; p += 4) glds16(wpack + p * 256 + lane * 4, wbuf + p * 256);
+    __syncthreads();
+
+    const float* xrow0 = xw + (0 * 16 + nl) * kXld + g;    // lane reads xp[n][h][v + g]
+    const float* xrow1 = xw + (1 * 16 + nl) * kXld + g;
+
+    int it = 0;
+    for (int pb = 0; pb < kNPB; ++pb) {
+        const int w0 = pb * kP;
+        f32x4 acc[kP][5];
+#pragma unroll
+        for (int a = 0; a < kP; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int cc = 0; cc < kNChunk; ++cc, ++it) {
+            const float* wb = wbuf + (it & 1) * kWChunkFloats + lane;
+            // prefetch the next chunk's weights into the other buffer by LDS-DMA (wraps to chunk 0
+            // for the next position block); every wave finished reading that buffer before the
+            // barrier that ended the previous chunk
+            {
+                const int nc = (cc + 1) & (kNChunk - 1);
+                const float* src = wpack + (size_t)nc * kWChunkFloats;
+                float* dst = wbuf + ((it + 1) & 1) * kWChunkFloats;
+                for (int p = q; p < kWChunkFloats / 256; p += 4) glds16(src + p * 256 + lane * 4, dst + p * 256);
+            }
+            const float a1 = a1pack[cc * 64 + lane];   // conv1 A operand: K1[c][g] (g<3) | b1[c] (g=3)
+#pragma unroll
+            for (int u = 0; u < kP + 2; ++u) {
+                const int wp = w0 + u;                 // padded position w' of y1p
+                if (wp < 2 || wp > 131) continue;      // zero padding of y1p: contributes nothing
+                const int v = wp - 2;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xv = (h == 0 ? xrow0 : xrow1)[v];
+                    const float b1f = (g == 3) ? 1.0f : xv;          // k = 3 carries the bias
+                    f32x4 X = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1f, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[r] = fmaxf(X[r], 0.f);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int wo = u - j;          // local output position: w = w' - j
+                        if (wo < 0 || wo >= kP) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int ot = 0; ot < 5; ++ot) {
+                                const float a = wb[(((h * 3 + j) * 5 + ot) * 4 + r) * 64];
+                                acc[wo][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, X[r], acc[wo][ot], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+            // __syncthreads() drains the LDS-DMA (vmcnt(0)) before the barrier
+            __syncthreads();
+        }
+        // ---- epilogue of the block: bias, ReLU, store feat[frame][w][o] ----
+        const long f = frame0 + nl;
+        if (f < n) {
+#pragma unroll
+            for (int a = 0; a < kP; ++a)
+#pragma unroll
+                for (int ot = 0; ot < 5; ++ot) {
+                    const int o = ot * 16 + g * 4;
+                    const float4 bb = *reinterpret_cast<const float4*>(b2 + o);
+                    float4 r;
+                    r.x = fmaxf(acc[a][ot][0] + bb.x, 0.f);
+                    r.y = fmaxf(acc[a][ot][1] + bb.y, 0.f);
+                    r.z = fmaxf(acc[a][ot][2] + bb.z, 0.f);
+                    r.w = fmaxf(acc[a][ot][3] + bb.w, 0.f);
+                    *reinterpret_cast<float4*>(feat + (f * kW2 + (w0 + a)) * kC2 + o) = r;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// f32 dense1: hid[f][n] = relu(sum_k feat[f][k] W1p[k][n] + c1[n]),  M = frames, K = 10560,
+// N = 256.  128x128 tile, BK = 32, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x4 tiles.
+// ------------------------------------------------------------------------------------
+constexpr int kDM = 128, kDN = 128, kDK = 32, kDld = 129;
+
+__global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restrict__ feat, long n,
+                                                            const float* __restrict__ w1p,   // [10560][256]
+                                                            const float* __restrict__ c1,    // [256]
+                                                            float* __restrict__ hid) {       // [n][256]
+    __shared__ float As[kDK][kDld];     // As[k][row]
+    __shared__ float Bs[kDK][kDld + 3]; // Bs[k][col]  (ld 132: float4 aligned rows)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long row0 = (long)blockIdx.x * kDM;
+    const int col0 = blockIdx.y * kDN;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < kFeat; k0 += kDK) {
+        // A tile: 128 rows x 32 k -> 1024 float4, 4 per thread, stored transposed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 3, k4 = (idx & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < n) v = *reinterpret_cast<const float4*>(feat + (row0 + r) * kFeat + k0 + k4);
+            As[k4 + 0][r] = v.x; As[k4 + 1][r] = v.y; As[k4 + 2][r] = v.z; As[k4 + 3][r] = v.w;
+        }
+        // B tile: 32 k x 128 cols -> 1024 float4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int k = idx >> 5, c4 = (idx & 31) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(w1p + (size_t)(k0 + k) * kHid + col0 + c4);
+            *reinterpret_cast<float4*>(&Bs[k][c4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kDK; kk += 4) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk + fq][wr * 64 + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk + fq][wc * 64 + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col0 + wc * 64 + j * 16 + fr;
+            const float bias = c1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = row0 + wr * 64 + i * 16 + fq * 4 + r;
+                if (row < n) hid[row * kHid + col] = fmaxf(acc[i][j][r] + bias, 0.f);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// head: logits = hid W2 + c2; softmax; first-max argmax (cnn.py:209).  64 frames per block,
+// 4 threads per frame (each 64 of the 256 hidden units), combined through LDS.
+// ------------------------------------------------------------------------------------
+constexpr int kMaxC = 32;
+
+__global__ __launch_bounds__(256) void vt_head_kernel(const float* __restrict__ hid, long n, int C,
+                                                      const float* __restrict__ w2,   // [256][C]
+                                                      const float* __restrict__ c2,   // [C]
+                                                      float* __restrict__ probs, int* __restrict__ labels,
+                                                      float* __restrict__ tap_logits) {
+    __shared__ float Ws[kHid * kMaxC];
+    __shared__ float part[4][64][kMaxC + 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kHid * C; i += 256) Ws[i] = w2[i];
+    const int fl = tid & 63, kq = tid >> 6;
+    const long f = (long)blockIdx.x * 64 + fl;
+    float s[kMaxC];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) s[c] = 0.f;
+    __syncthreads();
+    if (f < n) {
+        const float4* hp = reinterpret_cast<const float4*>(hid + f * kHid + kq * 64);
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const float4 hv = hp[k4];
+            const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* wrow = Ws + (kq * 64 + k4 * 4 + e) * C;
+#pragma unroll
+                for (int c = 0; c < kMaxC; ++c)
+                    if (c < C) s[c] = fmaf(hh[e], wrow[c], s[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+        if (c < C) part[kq][fl][c] = s[c];
+    __syncthreads();
+    if (kq == 0 && f < n) {
+        float z[kMaxC];
+        float mx = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) {
+                z[c] = ((part[0][fl][c] + part[1][fl][c]) + (part[2][fl][c] + part[3][fl][c])) + c2[c];
+                if (z[c] > mx) { mx = z[c]; arg = c; }     // strict '>' keeps the FIRST maximum
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) { z[c] = expf(z[c] - mx); sum += z[c]; }
+        const float inv = 1.0f / sum;
+        if (labels) labels[f] = arg;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) {
+                if (probs) probs[f * C + c] = z[c] * inv;
+            }
+    }
+    if (tap_logits && kq == 1 && f < n) {
+        for (int c = 0; c < C; ++c)
+            tap_logits[f * C + c] = ((part[0][fl][c] + part[1][fl][c]) + (part[2][fl][c] + part[3][fl][c])) + c2[c];
+    }
+}
+
+// feat[f][w][o] (f32 or bf16) -> reference layout (80,132) channels_first, f32   ('conv'/'flat' taps)
+template <typename T>
+__global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * kFeat) return;
+    const long f = i / kFeat;
+    const int r = (int)(i % kFeat);
+    const int o = r / kW2, w = r % kW2;
+    const T v = feat[(f * kW2 + w) * kC2 + o];
+    if constexpr (sizeof(T) == 2) out[i] = __uint_as_float(((unsigned)v) << 16);
+    else out[i] = v;
+}
+
+}  // namespace
+
+// ---- bf16 entry points (vtcnn2_bf16.hip) ------------------------------------------------
+int vtcnn2_bf16_pack(mdc_model* m);
+int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
+int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s);
+
+// d_pack slots: 0 conv2 weights, 1 conv1 operand, 2 conv2 bias, 3 dense1 weights (permuted),
+//               4 dense1 bias, 5 dense2 weights, 6 dense2 bias
+int vtcnn2_pack(mdc_model* m) {
+    const float* k1 = m->hk[0].data();   // OIHW (256,1,1,3)
+    const float* b1 = m->hb[0].data();
+    const float* k2 = m->hk[1].data();   // OIHW (80,256,2,3): ((o*256 + c)*2 + h)*3 + j
+    int rc;
+    if ((rc = upload(m, 2, m->hb[1].data(), kC2 * sizeof(float)))) return rc;
+    if ((rc = upload(m, 4, m->hb[2].data(), kHid * sizeof(float)))) return rc;
+    if ((rc = upload(m, 5, m->hk[3].data(), m->hk[3].size() * sizeof(float)))) return rc;
+    if ((rc = upload(m, 6, m->hb[3].data(), m->hb[3].size() * sizeof(float)))) return rc;
+    if (m->dtype == MDC_BF16) return vtcnn2_bf16_pack(m);
+
+    // conv2 weights: [chunk][h][j][ot][r][lane] = K2[16ot + (lane&15)][16chunk + 4(lane>>4) + r][h][j]
+    std::vector<float> wp((size_t)kNChunk * kWChunkFloats);
+    for (int cc = 0; cc < kNChunk; ++cc)
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 3; ++j)
+                for (int ot = 0; ot < 5; ++ot)
+                    for (int r = 0; r < 4; ++r)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int o = 16 * ot + (lane & 15), c = 16 * cc + 4 * (lane >> 4) + r;
+                            wp[(size_t)cc * kWChunkFloats + ((((h * 3 + j) * 5 + ot) * 4 + r) * 64) + lane] =
+                                k2[(((size_t)o * kC1 + c) * 2 + h) * 3 + j];
+                        }
+    if ((rc = upload(m, 0, wp.data(), wp.size() * sizeof(float)))) return rc;
+    // conv1 A operand per chunk: lane (c = lane&15, g = lane>>4): K1[16chunk + c][g] for g<3, b1 for g=3
+    std::vector<float> a1((size_t)kNChunk * 64);
+    for (int cc = 0; cc < kNChunk; ++cc)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int c = 16 * cc + (lane & 15), g = lane >> 4;
+            a1[cc * 64 + lane] = (g < 3) ? k1[c * 3 + g] : b1[c];
+        }
+    if ((rc = upload(m, 1, a1.data(), a1.size() * sizeof(float)))) return rc;
+    // dense1 rows permuted to the workspace order: row (w*80 + o) <- reference row (o*132 + w)
+    const float* w1 = m->hk[2].data();
+    std::vector<float> w1p((size_t)kFeat * kHid);
+    for (int w = 0; w < kW2; ++w)
+        for (int o = 0; o < kC2; ++o)
+            std::copy(w1 + (size_t)(o * kW2 + w) * kHid, w1 + (size_t)(o * kW2 + w + 1) * kHid,
+                      w1p.begin() + (size_t)(w * kC2 + o) * kHid);
+    return upload(m, 3, w1p.data(), w1p.size() * sizeof(float));
+}
+
+static size_t feat_elem(const mdc_model* m) { return m->dtype == MDC_BF16 ? 2 : 4; }
+
+size_t vtcnn2_workspace_bytes(const mdc_model* m, int64_t n) {
+    const size_t f = ((size_t)n * kFeat * feat_elem(m) + 255) & ~(size_t)255;
+    const size_t h = ((size_t)n * kHid * sizeof(float) + 255) & ~(size_t)255;
+    return f + h;
+}
+
+int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
+                   float* tap, int tap_kind, void* ws, size_t ws_bytes, hipStream_t s) {
+    const size_t need = vtcnn2_workspace_bytes(m, n);
+    if (!ws || ws_bytes < need) { set_error("vtcnn2 forward of %lld frames needs %zu workspace bytes (got %zu)", (long long)n, need, ws_bytes); return MDC_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) { set_error("workspace must be 256-byte aligned"); return MDC_EINVAL; }
+    const size_t fbytes = ((size_t)n * kFeat * feat_elem(m) + 255) & ~(size_t)255;
+    void* feat = ws;
+    float* hid = reinterpret_cast<float*>(static_cast<char*>(ws) + fbytes);
+    const int C = m->topo.classes;
+    int rc;
+    if (m->dtype == MDC_BF16) {
+        { ProfScope ps(m, 0, s); if ((rc = vtcnn2_bf16_conv(m, x, n, feat, s))) return rc; }
+        { ProfScope ps(m, 1, s); if ((rc = vtcnn2_bf16_dense1(m, feat, n, hid, s))) return rc; }
+    } else {
+        {
+            ProfScope ps(m, 0, s);
+            static bool attr_set = false;
+            if (!attr_set) {
+                MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(vt_conv_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), kConvF32Lds, s, x, (long)n,
+                               static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]),
+                               static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat));
+            MDC_HIP(hipGetLastError());
+        }
+        {
+            ProfScope ps(m, 1, s);
+            hipLaunchKernelGGL(vt_dense1_f32_kernel, dim3((unsigned)((n + kDM - 1) / kDM), kHid / kDN), dim3(256), 0, s,
+                               static_cast<const float*>(feat), (long)n, static_cast<const float*>(m->d_pack[3]),
+                               static_cast<const float*>(m->d_pack[4]), hid);
+            MDC_HIP(hipGetLastError());
+        }
+    }
+    {
+        ProfScope ps(m, 2, s);
+        hipLaunchKernelGGL(vt_head_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, hid, (long)n, C,
+                           static_cast<const float*>(m->d_pack[5]), static_cast<const float*>(m->d_pack[6]), probs, labels,
+                           tap_kind == MDC_TAP_DENSE ? tap : nullptr);
+        MDC_HIP(hipGetLastError());
+    }
+    if (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) {
+        const long total = (long)n * kFeat;
+        if (m->dtype == MDC_BF16)
+            hipLaunchKernelGGL(vt_unpermute_kernel<unsigned short>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned short*>(feat), (long)n, tap);
+        else
+            hipLaunchKernelGGL(vt_unpermute_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(feat), (long)n, tap);
+        MDC_HIP(hipGetLastError());
+    } else if (tap_kind == MDC_TAP_HIDDEN) {
+        MDC_HIP(hipMemcpyAsync(tap, hid, (size_t)n * kHid * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return MDC_OK;
+}
+
+}  // namespace mdc

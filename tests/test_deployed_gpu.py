@@ -124,9 +124,12 @@ def test_first_max_tie_break_and_relu_zero():
     assert (m.predict(x, tap="dense") == 0).all()
     assert (m.predict_classes(x) == 0).all()
     np.testing.assert_array_equal(m.predict(x), np.full((257, 3), np.float32(1 / 3)))
-    # two-way tie between classes 1 and 2, class 0 lower -> label 1
-    db[:] = [0.0, 1.0, 1.0]
+    # exact two-way tie between classes 1 and 2 (identical columns), class 0 lower -> label 1
+    dk[:, 2] = dk[:, 1]
+    db[:] = [0.0, 100.0, 100.0]
     m.set_weights([(ck, cb), (dk, db)])
+    d = m.predict(x, tap="dense")
+    assert (d[:, 1] == d[:, 2]).all() and (d[:, 1] > d[:, 0]).all()
     assert (m.predict_classes(x) == 1).all()
 
 

@@ -1,0 +1,114 @@
+"""Parity of the canonical VT-CNN2 HIP path (conv1+conv2 MFMA kernel, dense1 GEMM, softmax head)
+against the CPU oracle, through the C ABI.  No reference outputs exist for this topology (no
+weights are bundled): parity is against this repo's f64 oracle ("parity unpinned").
+
+Tolerances (relative to the largest |logit| of the batch, since the net is positively
+homogeneous in its input scale):
+  f32 path : 2e-5   (exact-f32 MFMA fma chains, K up to 10560)
+  bf16 path: 2e-2   (bf16 operands, f32 accumulation)
+Labels: bit-exact wherever the oracle's top-2 logit margin exceeds 4x the tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames, synthetic_weights
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 2e-5, "bf16": 2e-2}
+_cache = {}
+
+
+def _setup(classes, seed=2016, bias_scale=0.0):
+    key = (classes, seed, bias_scale)
+    if key not in _cache:
+        topo = Topology.vtcnn2(classes)
+        _cache[key] = (topo, synthetic_weights(topo, seed=seed, bias_scale=bias_scale))
+    return _cache[key]
+
+
+def _model(classes, dtype, **kw):
+    topo, w = _setup(classes, **kw)
+    m = VTCNN2(topo, dtype=dtype)
+    m.set_weights(w)
+    return m, w
+
+
+def _check(m, w, x, dtype, batch_size=None):
+    ref = O.forward("vtcnn2", x, w, dtype=np.float64)
+    scale = float(np.abs(ref["logits"]).max())
+    tol = TOL[dtype]
+    lg = m.predict(x, tap="dense", batch_size=batch_size)
+    assert np.abs(lg - ref["logits"]).max() <= tol * scale, (np.abs(lg - ref["logits"]).max() / scale)
+    p = m.predict(x, batch_size=batch_size)
+    assert np.abs(p - ref["probs"]).max() <= max(2e-6, 2 * tol * scale)
+    np.testing.assert_allclose(p.sum(axis=1), 1.0, atol=1e-5)
+    lab = m.predict_classes(x, batch_size=batch_size)
+    srt = np.sort(ref["logits"], axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 4 * tol * scale
+    assert (lab[decided] == ref["labels"][decided]).all()
+    # argmax must be the first max of OUR probabilities
+    assert (lab == np.argmax(p, axis=1)).all()
+    return ref, decided.mean()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("classes", [3, 11])
+@pytest.mark.parametrize("n", [1, 16, 17, 64, 100, 257])
+def test_parity(dtype, classes, n):
+    m, w = _model(classes, dtype)
+    x = synthetic_frames(n, seed=2016)
+    _check(m, w, x, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_parity_with_biases_and_large_inputs(dtype):
+    m, w = _model(11, dtype, seed=5, bias_scale=0.05)
+    x = synthetic_frames(96, seed=7, sigma=0.5)
+    _check(m, w, x, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_taps(dtype):
+    m, w = _model(11, dtype, seed=5, bias_scale=0.05)
+    x = synthetic_frames(40, seed=3, sigma=0.1)
+    ref = O.forward("vtcnn2", x, w, dtype=np.float64, taps=True)
+    tol = TOL[dtype]
+    flat = m.predict(x, tap="flat")
+    assert flat.shape == (40, 10560)
+    assert np.abs(flat - ref["flat"]).max() <= tol * np.abs(ref["flat"]).max()
+    conv = m.predict(x, tap="conv")
+    assert conv.shape == (40, 80, 132)
+    np.testing.assert_array_equal(conv.reshape(40, -1), flat)
+    hid = m.predict(x, tap="hidden")
+    assert hid.shape == (40, 256)
+    assert np.abs(hid - ref["dense1"]).max() <= tol * np.abs(ref["dense1"]).max()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_batch_size_invariance(dtype):
+    m, w = _model(11, dtype)
+    x = synthetic_frames(300, seed=11, device="cuda")
+    a = m.predict(x)
+    for bs in (16, 100, 299):
+        assert torch.equal(a, m.predict(x, batch_size=bs))
+    la = m.predict_classes(x)
+    assert torch.equal(la, m.predict_classes(x, batch_size=64))
+
+
+def test_zero_input_and_relu_exact_zero():
+    # zero frames, zero biases: every activation is exactly 0 -> logits 0 -> uniform softmax, label 0
+    for dtype in ("f32", "bf16"):
+        m, _ = _model(11, dtype)
+        x = np.zeros((20, 2, 128), np.float32)
+        p = m.predict(x)
+        np.testing.assert_array_equal(p, np.full((20, 11), np.float32(1.0) / np.float32(11.0)))
+        assert (m.predict_classes(x) == 0).all()
+
+
+def test_f32_larger_batch_statistics():
+    m, w = _model(3, "f32")
+    x = synthetic_frames(1500, seed=99)
+    _, frac = _check(m, w, x, "f32")
+    assert frac > 0.999
