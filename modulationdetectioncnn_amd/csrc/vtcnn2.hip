@@ -366,9 +366,8 @@ int vtcnn2_pack(mdc_model* m) {
 static size_t feat_elem(const mdc_model* m) { return m->dtype == MDC_BF16 ? 2 : 4; }
 
 size_t vtcnn2_workspace_bytes(const mdc_model* m, int64_t n) {
-    const size_t f = ((size_t)n * kFeat * feat_elem(m) + 255) & ~(size_t)255;
-    const size_t h = ((size_t)n * kHid * sizeof(float) + 255) & ~(size_t)255;
-    return f + h;
+    const size_t np = ((size_t)n + 255) & ~(size_t)255;   // kernels write whole 16-frame groups / 256-row tiles
+    return np * kFeat * feat_elem(m) + np * kHid * sizeof(float);
 }
 
 int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
@@ -376,7 +375,7 @@ int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, 
     const size_t need = vtcnn2_workspace_bytes(m, n);
     if (!ws || ws_bytes < need) { set_error("vtcnn2 forward of %lld frames needs %zu workspace bytes (got %zu)", (long long)n, need, ws_bytes); return MDC_EINVAL; }
     if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) { set_error("workspace must be 256-byte aligned"); return MDC_EINVAL; }
-    const size_t fbytes = ((size_t)n * kFeat * feat_elem(m) + 255) & ~(size_t)255;
+    const size_t fbytes = (((size_t)n + 255) & ~(size_t)255) * kFeat * feat_elem(m);
     void* feat = ws;
     float* hid = reinterpret_cast<float*>(static_cast<char*>(ws) + fbytes);
     const int C = m->topo.classes;

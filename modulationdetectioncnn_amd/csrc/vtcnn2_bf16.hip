@@ -23,6 +23,7 @@
 // over the banks), two LDS buffers, 8 waves (2 x 4), fused bias + ReLU epilogue.
 #include "mdc_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -57,48 +58,38 @@ __device__ __forceinline__ float bf16_hi_as_f32(float a) {             // value 
     return __uint_as_float(pack2(a, 0.f) << 16);
 }
 
-struct Stage {            // one thread's share of a 16-frame group: 4 float4 loads
-    float4 v[4];
-};
-
-__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ x, long n, long frame0, int tid) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k;
-        const long f = frame0 + (idx >> 6);
-        st.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < n) st.v[k] = reinterpret_cast<const float4*>(x + f * kFrameFloats)[idx & 63];
-    }
-}
-
-// image word for lane (frame i, k-group kg): kg 0 = bf16 hi pair, kg 1 = lo pair (x - hi), kg 2 = hi pair
+// Staging of a 16-frame group: 1024 float4 = 4 per thread, done one float4 ("quarter" k) at a time so
+// that the few registers it needs are live only briefly (the main loop sits at the register limit).
+// Image word for lane (frame i, k-group kg): kg 0 = bf16 hi pair, kg 1 = lo pair (x - hi), kg 2 = hi pair
 // again (multiplied by the low halves of the taps), kg 3 = constant (1,1) (bias slots; written once).
-__device__ __forceinline__ void stage_write(const Stage& st, unsigned* __restrict__ im, int tid) {
+__device__ __forceinline__ void stage_quarter(int k, const float* __restrict__ x, long n, long frame0,
+                                              unsigned* __restrict__ im, int tid) {
+    const int idx = tid + 256 * k;
+    const int i = idx >> 6, l = idx & 63;
+    const long f = frame0 + i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < n) v = reinterpret_cast<const float4*>(x + f * kFrameFloats)[l];
+    const int h = l >> 5, m = l & 31;
+    const float xs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k;
-        const int i = idx >> 6, l = idx & 63;
-        const int h = l >> 5, m = l & 31;
-        const float xs[4] = {st.v[k].x, st.v[k].y, st.v[k].z, st.v[k].w};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float a = xs[2 * e], b = xs[2 * e + 1];
-            const unsigned hi = pack2(a, b);
-            const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
-            const unsigned lo = pack2(a - ah, b - bh);
-            unsigned* d = im + (h * kPairs + 2 * m + 1 + e) * 64 + i;   // samples 4m+2e, +1 -> padded 4m+2e+2
-            d[0] = hi;
-            d[16] = lo;
-            d[32] = hi;
-        }
+    for (int e = 0; e < 2; ++e) {
+        const float a = xs[2 * e], b = xs[2 * e + 1];
+        const unsigned hi = pack2(a, b);
+        const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
+        const unsigned lo = pack2(a - ah, b - bh);
+        unsigned* d = im + (h * kPairs + 2 * m + 1 + e) * 64 + i;   // samples 4m+2e, +1 -> padded 4m+2e+2, +3
+        d[0] = hi;
+        d[16] = lo;
+        d[32] = hi;
     }
 }
 
+template <int ABL>   // 0 = product; 1/2/3 = timing-only ablations (MDC_ABLATE env, results wrong)
 __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __restrict__ x, long n,
                                                               const u32x4* __restrict__ wq,   // [4][60][64]
-                                                              const u32x2* __restrict__ a1q,  // [4][4][2][64]
+                                                              const u32x2* __restrict__ a1q,  // [4][4][64]
                                                               const float* __restrict__ b2,   // [80]
-                                                              unsigned short* __restrict__ feat) {   // [n][132][80] bf16
+                                                              unsigned short* __restrict__ feat) {   // [ceil16(n)][132][80] bf16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* img = reinterpret_cast<unsigned*>(smem);
     float* part = reinterpret_cast<float*>(smem + (size_t)2 * kImgWords * 4);
@@ -117,13 +108,14 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
 #pragma unroll
                 for (int ot = 0; ot < 5; ++ot)
                     W[h][j][cp][ot] = __builtin_bit_cast(bf16x8, wq[(q * kWFrags + ((h * 3 + j) * 2 + cp) * 5 + ot) * 64 + lane]);
-    s16x4 A1[4][2];
+    s16x4 A1[4];          // taps at k-slots 0..2 (even positions); odd positions shift the B operand instead
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int par = 0; par < 2; ++par) A1[ct][par] = __builtin_bit_cast(s16x4, a1q[((q * 4 + ct) * 2 + par) * 64 + lane]);
-    const float4 bq = *reinterpret_cast<const float4*>(b2 + 16 * q + 4 * g);     // this wave reduces output tile q ...
-    const float4 b4 = *reinterpret_cast<const float4*>(b2 + 64 + 4 * g);         // ... and tile 4 on its turn
+    for (int ct = 0; ct < 4; ++ct) A1[ct] = __builtin_bit_cast(s16x4, a1q[(q * 4 + ct) * 64 + lane]);
+    float4 bq = *reinterpret_cast<const float4*>(b2 + 16 * q + 4 * g);     // this wave reduces output tile q ...
+    float b4q = b2[64 + 4 * g + q];                                         // ... and component q of tile 4
+    // consume the loads here: otherwise their first use inside the main loop carries an s_waitcnt vmcnt(N)
+    // that also waits for the previous steps' feature STORES (vmcnt is in-order) on every iteration
+    asm volatile("" : "+v"(bq.x), "+v"(bq.y), "+v"(bq.z), "+v"(bq.w), "+v"(b4q));
 
     // ---- LDS init: zero padding pairs and the constant bias-slot lanes, both buffers ----
     for (int i = tid; i < 2 * kImgWords; i += 256) img[i] = ((i & 63) >= 48) ? 0x3F803F80u : 0u;
@@ -131,11 +123,8 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
 
     const long ngroups = (n + 15) >> 4;
     long grp = blockIdx.x;
-    Stage st;
-    if (grp < ngroups) {
-        stage_load(st, x, n, grp * 16, tid);
-        stage_write(st, img, tid);
-    }
+    if (grp < ngroups)
+        for (int k = 0; k < 4; ++k) stage_quarter(k, x, n, grp * 16, img, tid);
     __syncthreads();
 
     int buf = 0;
@@ -143,7 +132,6 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         const unsigned* im = img + buf * kImgWords + lane;
         const long frame0 = grp * 16;
         const long fme = frame0 + nl;
-        const bool fvalid = fme < n;
         unsigned short* fbase = feat + fme * (long)(kW2 * kC2) + 4 * g;
         const long gnext = grp + gridDim.x;
 
@@ -153,85 +141,160 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
 #pragma unroll
             for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         bf16x8 Bf[2][2];
+        f32x4 X[4][2];        // conv1 tiles [channel tile][row]; row 0 and row 1 are live at different times
+        f32x4 rp[4];
+        float rc[4];
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
 
         // conv1 at output index v (padded position v+2): pair index i = v>>1, taps start at slot v&1
-        auto conv1_pack = [&](int v, auto par_tag) {
-            constexpr int PAR = decltype(par_tag)::value;
-            const int i = v >> 1;
-            s16x4 bI = __builtin_bit_cast(s16x4, u32x2{im[(0 * kPairs + i) * 64], im[(0 * kPairs + i + 1) * 64]});
-            s16x4 bQ = __builtin_bit_cast(s16x4, u32x2{im[(1 * kPairs + i) * 64], im[(1 * kPairs + i + 1) * 64]});
-            f32x4 X[4][2];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                X[ct][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A1[ct][PAR], bI, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                X[ct][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A1[ct][PAR], bQ, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // The builtin's result always lands in AGPRs in this kernel (512-register budget) and every value
+        // then costs a v_accvgpr_read before the VALU can convert it; the asm form names a VGPR destination.
+        // hipcc neither counts wait states for asm nor knows this MFMA's latency: x_fence(h) supplies the
+        // XDL-write -> VALU-read wait states before the first pack of row h.
+        auto conv1 = [&](int v, auto par_tag, auto h_tag) {
+            constexpr int PAR = decltype(par_tag)::value, h = decltype(h_tag)::value;
+            const unsigned* pi = im + (h * kPairs + (v >> 1)) * 64;
+            u32x2 b;
+            if (PAR == 0) {
+                b = u32x2{pi[0], pi[64]};                        // samples v, v+1 | v+2, v+3
+            } else {                                             // odd v: start one sample later
+                const unsigned p0 = pi[0], p1 = pi[64], p2 = pi[128];
+                b = u32x2{__builtin_amdgcn_alignbit(p1, p0, 16), __builtin_amdgcn_alignbit(p2, p1, 16)};
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int cp = 0; cp < 2; ++cp) {
-                    const f32x4 t0 = X[2 * cp][h], t1 = X[2 * cp + 1][h];
-                    Bf[h][cp] = __builtin_bit_cast(bf16x8, u32x4{pack2relu(t0[0], t0[1]), pack2relu(t0[2], t0[3]),
-                                                                 pack2relu(t1[0], t1[1]), pack2relu(t1[2], t1[3])});
-                }
+            for (int ct = 0; ct < 4; ++ct) {
+                f32x4& xd = X[ct][h];            // (asm operands cannot name captured arrays directly)
+                const s16x4& a1 = A1[ct];
+                // "=&v": the result must not share registers with an operand; s_nop 1: a VALU (v_alignbit)
+                // may have written the B operand in the previous cycle (2 wait states, VALU write -> MFMA read)
+                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xd) : "v"(a1), "v"(b));
+            }
         };
-        // conv2 of one position: tap j accumulates into the output at w'-j
-        auto conv2 = [&](f32x4 (&a0)[5], f32x4 (&a1)[5], f32x4 (&a2)[5]) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-                    for (int ot = 0; ot < 5; ++ot) {
-                        const f32x4 c0 = (h == 0 && cp == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : a0[ot];
-                        a0[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[h][0][cp][ot], Bf[h][cp], c0, 0, 0, 0);
-                        a1[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[h][1][cp][ot], Bf[h][cp], a1[ot], 0, 0, 0);
-                        a2[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[h][2][cp][ot], Bf[h][cp], a2[ot], 0, 0, 0);
-                    }
+        auto x_fence = [&](auto h_tag) {
+            constexpr int h = decltype(h_tag)::value;
+            f32x4 &x0 = X[0][h], &x1 = X[1][h], &x2 = X[2][h], &x3 = X[3][h];
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
         };
-        // publish this wave's K-quarter partial of output position w, then (after the barrier)
-        // finish the tiles this wave owns: sum of the 4 partials, bias, ReLU, bf16, store
-        auto flush = [&](int w, const f32x4 (&a)[5]) {
-            float* pw = part + (w & 1) * kPartFloats;
+        // ReLU + bf16 of the conv1 tile pair (row h, channel pair cp): already a B operand
+        auto pack = [&](auto h_tag, auto cp_tag) {
+            constexpr int h = decltype(h_tag)::value, cp = decltype(cp_tag)::value;
+            if (ABL == 2) return;
+            const f32x4 t0 = X[2 * cp][h], t1 = X[2 * cp + 1][h];
+            Bf[h][cp] = __builtin_bit_cast(bf16x8, u32x4{pack2relu(t0[0], t0[1]), pack2relu(t0[2], t0[3]),
+                                                         pack2relu(t1[0], t1[1]), pack2relu(t1[2], t1[3])});
+        };
+        // conv2, one tap j of one (row, channel pair): 5 MFMAs into the accumulators of output w'-j
+        auto tap = [&](auto j_tag, auto h_tag, auto cp_tag, f32x4 (&a)[5], bool fresh) {
+            constexpr int j = decltype(j_tag)::value, h = decltype(h_tag)::value, cp = decltype(cp_tag)::value;
+#pragma unroll
+            for (int ot = 0; ot < 5; ++ot) {
+                const f32x4 c = fresh ? f32x4{0.f, 0.f, 0.f, 0.f} : a[ot];
+                a[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[h][j][cp][ot], Bf[h][cp], c, 0, 0, 0);
+            }
+        };
+        // ---- exchange of the four waves' K-quarter partials of ONE output position.  Wave q owns
+        // output tile q (a float4 per lane) and component q of every float4 of tile 4, so all four
+        // waves do identical, branch-free work.
+        auto part_write = [&](auto pb_tag, const f32x4 (&a)[5]) {
+            constexpr int PB = decltype(pb_tag)::value;
+            if (ABL == 1) {   // keep the accumulators live, skip exchange/barrier/store
+                for (int ot = 0; ot < 5; ++ot) asm volatile("" ::"a"(a[ot]));
+                return;
+            }
+            float* pw = part + PB * kPartFloats;
 #pragma unroll
             for (int ot = 0; ot < 5; ++ot) *reinterpret_cast<f32x4*>(pw + ((q * 5 + ot) * 64 + lane) * 4) = a[ot];
-            __syncthreads();
-            auto finish = [&](int ot, const float4& bias) {
-                const f32x4 p0 = *reinterpret_cast<const f32x4*>(pw + ((0 * 5 + ot) * 64 + lane) * 4);
-                const f32x4 p1 = *reinterpret_cast<const f32x4*>(pw + ((1 * 5 + ot) * 64 + lane) * 4);
-                const f32x4 p2 = *reinterpret_cast<const f32x4*>(pw + ((2 * 5 + ot) * 64 + lane) * 4);
-                const f32x4 p3 = *reinterpret_cast<const f32x4*>(pw + ((3 * 5 + ot) * 64 + lane) * 4);
-                const f32x4 s = (p0 + p1) + (p2 + p3);
-                u32x2 o;
-                o[0] = pack2relu(s[0] + bias.x, s[1] + bias.y);
-                o[1] = pack2relu(s[2] + bias.z, s[3] + bias.w);
-                if (fvalid) *reinterpret_cast<u32x2*>(fbase + (long)w * kC2 + 16 * ot) = o;
-            };
-            finish(q, bq);
-            if (q == (w & 3)) finish(4, b4);
         };
-
+        auto red_load = [&](auto pb_tag) {
+            constexpr int PB = decltype(pb_tag)::value;
+            if (ABL == 1) return;
+            __syncthreads();     // s_waitcnt lgkmcnt(0) + s_barrier: every wave's partial(w) is in LDS
+            const float* pw = part + PB * kPartFloats;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rp[k] = *reinterpret_cast<const f32x4*>(pw + ((k * 5 + q) * 64 + lane) * 4);
+                rc[k] = pw[((k * 5 + 4) * 64 + lane) * 4 + q];
+            }
+        };
+        auto red_finish = [&](int w) {
+            if (ABL == 1) return;
+            const f32x4 s = (rp[0] + rp[1]) + (rp[2] + rp[3]);
+            u32x2 o;
+            o[0] = pack2relu(s[0] + bq.x, s[1] + bq.y);
+            o[1] = pack2relu(s[2] + bq.z, s[3] + bq.w);
+            unsigned short* dst = fbase + (long)w * kC2;
+            *reinterpret_cast<u32x2*>(dst + 16 * q) = o;
+            const float t = ((rc[0] + rc[1]) + (rc[2] + rc[3])) + b4q;
+            dst[64 + q] = (unsigned short)pack2relu(t, 0.f);
+        };
+#define MDC_SB() do { if (ABL != 3) __builtin_amdgcn_sched_barrier(0); } while (0)
+        // One position step v (outputs: a0 = v+2 fresh, a1 = v+1, a2 = v completes).  TAP-MAJOR order:
+        //   R1  tap 2 (20 MFMAs) -> a2 is complete; finish of output v-1 rides along
+        //   R2  a2 -> LDS (its registers are not written again before R4's lgkmcnt(0) of the NEXT step:
+        //       an MFMA that overwrites the source of an in-flight ds_write corrupts it, and hipcc does
+        //       not model that hazard); conv1 operand reads for v+1
+        //   R3  conv1(v+1) (8 MFMAs) + tap 1 (20 MFMAs)
+        //   R4  barrier; owner's reads of partial(v)
+        //   R5  tap 0 (20 MFMAs) with the ReLU/bf16 pack of conv1(v+1) trailing one group behind
+        // sched_barrier pins the phases: at the register limit hipcc otherwise sinks every LDS read next to
+        // its use and exposes the LDS latency several times per step.
+        auto step = [&](int v, auto par_next, auto first_tag, auto last_tag, f32x4 (&a0)[5], f32x4 (&a1)[5], f32x4 (&a2)[5]) {
+            constexpr bool FIRST = decltype(first_tag)::value != 0, LAST = decltype(last_tag)::value != 0;
+            using PB = std::integral_constant<int, 1 - decltype(par_next)::value>;      // = v & 1
+            // R1: tap 2 (20 MFMAs) + pack of row 1 of this step's conv1 (issued late in the previous step)
+            if (!FIRST) { x_fence(I1{}); pack(I1{}, I0{}); pack(I1{}, I1{}); }
+            tap(I2{}, I0{}, I0{}, a2, false); tap(I2{}, I0{}, I1{}, a2, false);
+            tap(I2{}, I1{}, I0{}, a2, false); tap(I2{}, I1{}, I1{}, a2, false);
+            MDC_SB();
+            // R2: the completed output goes to LDS
+            part_write(PB{}, a2);
+            MDC_SB();
+            // R3: conv1(v+1) row 0 + tap 1 (20 MFMAs) + finish of output v-1
+            if (!LAST) conv1(v + 1, par_next, I0{});
+            tap(I1{}, I0{}, I0{}, a1, false); tap(I1{}, I0{}, I1{}, a1, false);
+            if (!FIRST) red_finish(v - 1);
+            tap(I1{}, I1{}, I0{}, a1, false); tap(I1{}, I1{}, I1{}, a1, false);
+            MDC_SB();
+            // R4: barrier + owner's reads of partial(v)
+            red_load(PB{});
+            MDC_SB();
+            // R5: tap 0 (20 MFMAs) + pack of row 0 + conv1(v+1) row 1
+            tap(I0{}, I0{}, I0{}, a0, true);
+            if (!LAST) x_fence(I0{});
+            tap(I0{}, I0{}, I1{}, a0, false); if (!LAST) pack(I0{}, I0{});
+            tap(I0{}, I1{}, I0{}, a0, false); if (!LAST) pack(I0{}, I1{});
+            if (!LAST) conv1(v + 1, par_next, I1{});
+            tap(I0{}, I1{}, I1{}, a0, false);
+            MDC_SB();
+        };
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
-        conv1_pack(0, P0{});
-        int v = 0;
-        for (int it = 0; it < 21; ++it, v += 6) {
-            if (it == 8 && gnext < ngroups) stage_load(st, x, n, gnext * 16, tid);
-            if (it == 16 && gnext < ngroups) stage_write(st, img + (buf ^ 1) * kImgWords, tid);
-            conv2(acc[2], acc[1], acc[0]); conv1_pack(v + 1, P1{}); flush(v + 0, acc[0]);
-            conv2(acc[0], acc[2], acc[1]); conv1_pack(v + 2, P0{}); flush(v + 1, acc[1]);
-            conv2(acc[1], acc[0], acc[2]); conv1_pack(v + 3, P1{}); flush(v + 2, acc[2]);
-            conv2(acc[2], acc[1], acc[0]); conv1_pack(v + 4, P0{}); flush(v + 3, acc[0]);
-            conv2(acc[0], acc[2], acc[1]); conv1_pack(v + 5, P1{}); flush(v + 4, acc[1]);
-            conv2(acc[1], acc[0], acc[2]); conv1_pack(v + 6, P0{}); flush(v + 5, acc[2]);
+
+        conv1(0, P0{}, I0{}); conv1(0, P0{}, I1{});
+        x_fence(I0{}); x_fence(I1{});
+        pack(I0{}, I0{}); pack(I0{}, I1{}); pack(I1{}, I0{}); pack(I1{}, I1{});
+        step(0, P1{}, I1{}, I0{}, acc[2], acc[1], acc[0]);
+        int v = 1;
+        for (int it = 0; it < 21; ++it, v += 6) {     // v = 1 .. 126
+            if (it >= 12 && it < 16 && gnext < ngroups)      // next group's frames -> the other image buffer
+                stage_quarter(it - 12, x, n, gnext * 16, img + (buf ^ 1) * kImgWords, tid);
+            step(v + 0, P0{}, I0{}, I0{}, acc[0], acc[2], acc[1]);
+            step(v + 1, P1{}, I0{}, I0{}, acc[1], acc[0], acc[2]);
+            step(v + 2, P0{}, I0{}, I0{}, acc[2], acc[1], acc[0]);
+            step(v + 3, P1{}, I0{}, I0{}, acc[0], acc[2], acc[1]);
+            step(v + 4, P0{}, I0{}, I0{}, acc[1], acc[0], acc[2]);
+            step(v + 5, P1{}, I0{}, I0{}, acc[2], acc[1], acc[0]);
         }
-        // v = 126..129 (conv1_pack(126) already done), then the two outputs fed only by padding beyond
-        conv2(acc[2], acc[1], acc[0]); conv1_pack(127, P1{}); flush(126, acc[0]);
-        conv2(acc[0], acc[2], acc[1]); conv1_pack(128, P0{}); flush(127, acc[1]);
-        conv2(acc[1], acc[0], acc[2]); conv1_pack(129, P1{}); flush(128, acc[2]);
-        conv2(acc[2], acc[1], acc[0]);                         flush(129, acc[0]);
-        flush(130, acc[1]);
-        flush(131, acc[2]);
+        step(127, P0{}, I0{}, I0{}, acc[0], acc[2], acc[1]);
+        step(128, P1{}, I0{}, I0{}, acc[1], acc[0], acc[2]);
+        step(129, P0{}, I0{}, I1{}, acc[2], acc[1], acc[0]);
+        red_finish(129);
+        // outputs 130 and 131 see only zero padding beyond position 131: complete as they are
+        part_write(I0{}, acc[1]); red_load(I0{}); red_finish(130);
+        part_write(I1{}, acc[2]); red_load(I1{}); red_finish(131);
+#undef MDC_SB
         __syncthreads();      // next group's image is complete; partial buffers are free again
     }
 }
@@ -376,27 +439,26 @@ int vtcnn2_bf16_pack(mdc_model* m) {
                                 wq[idx] = f2bf(k2[(((size_t)o * kC1 + ch) * 2 + h) * 3 + j]);
                             }
     if ((rc = upload(m, 0, wq.data(), wq.size() * 2))) return rc;
-    // conv1 A-fragments (K = 16): [q][ct][par][lane][4]; lane (c = lane&15, kg = lane>>4):
-    //   kg 0: tap hi at slots par..par+2 (x hi)   kg 1: tap hi (x lo)   kg 2: tap lo (x hi)   kg 3: (b1 hi, b1 lo, 0, 0)
-    std::vector<unsigned short> a1((size_t)4 * 4 * 2 * 64 * 4, 0);
+    // conv1 A-fragments (K = 16): [q][ct][lane][4]; lane (c = lane&15, kg = lane>>4), taps at slots 0..2:
+    //   kg 0: tap hi (x hi)   kg 1: tap hi (x lo)   kg 2: tap lo (x hi)   kg 3: (b1 hi, b1 lo, 0, 0) (x = 1)
+    std::vector<unsigned short> a1((size_t)4 * 4 * 64 * 4, 0);
     for (int q = 0; q < 4; ++q)
         for (int ct = 0; ct < 4; ++ct)
-            for (int par = 0; par < 2; ++par)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int ch = 64 * q + 16 * ct + (lane & 15), kg = lane >> 4;
-                    unsigned short* d = &a1[((((size_t)q * 4 + ct) * 2 + par) * 64 + lane) * 4];
-                    if (kg == 3) {
-                        const unsigned short hi = f2bf(b1[ch]);
-                        d[0] = hi;
-                        d[1] = f2bf(b1[ch] - bf2f(hi));
-                    } else {
-                        for (int t = 0; t < 3; ++t) {
-                            const float kv = k1[ch * 3 + t];
-                            const unsigned short hi = f2bf(kv);
-                            d[par + t] = (kg == 2) ? f2bf(kv - bf2f(hi)) : hi;
-                        }
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = 64 * q + 16 * ct + (lane & 15), kg = lane >> 4;
+                unsigned short* d = &a1[(((size_t)q * 4 + ct) * 64 + lane) * 4];
+                if (kg == 3) {
+                    const unsigned short hi = f2bf(b1[ch]);
+                    d[0] = hi;
+                    d[1] = f2bf(b1[ch] - bf2f(hi));
+                } else {
+                    for (int t = 0; t < 3; ++t) {
+                        const float kv = k1[ch * 3 + t];
+                        const unsigned short hi = f2bf(kv);
+                        d[t] = (kg == 2) ? f2bf(kv - bf2f(hi)) : hi;
                     }
                 }
+            }
     if ((rc = upload(m, 1, a1.data(), a1.size() * 2))) return rc;
     // dense1: transposed [n][k'] with k' = w*80 + o  <-  reference row o*132 + w
     const float* w1 = m->hk[2].data();
@@ -410,16 +472,16 @@ int vtcnn2_bf16_pack(mdc_model* m) {
 }
 
 int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds));
-        attr_set = true;
-    }
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-    hipLaunchKernelGGL(vt_conv_bf16_kernel, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n,
-                       static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]),
-                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat));
+    static const int abl = getenv("MDC_ABLATE") ? atoi(getenv("MDC_ABLATE")) : 0;
+#define MDC_LAUNCH_CONV(A) do { \
+    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds)); \
+    hipLaunchKernelGGL(vt_conv_bf16_kernel<A>, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n, \
+                       static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]), \
+                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat)); } while (0)
+    if (abl == 1) MDC_LAUNCH_CONV(1); else if (abl == 2) MDC_LAUNCH_CONV(2); else if (abl == 3) MDC_LAUNCH_CONV(3); else MDC_LAUNCH_CONV(0);
+#undef MDC_LAUNCH_CONV
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Timing-only ablations of the bf16 conv kernel (MDC_ABLATE=1: no exchange/barrier/store,
+2: no conv1+pack).  Results are wrong by construction; only the kernel time is read."""
+import os, subprocess, sys, json
+for abl in ("0", "1", "2"):
+    env = dict(os.environ, MDC_ABLATE=abl)
+    r = subprocess.run([sys.executable, "bench.py", "--no-extras", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True)
+    try:
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        print("ABLATE", abl, {k: round(v["ms_per_step"], 2) for k, v in j["kernels"].items()}, "value %.3g" % j["value"], flush=True)
+    except Exception as e:
+        print("ABLATE", abl, "failed", e, r.stderr[-500:])
