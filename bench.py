@@ -57,6 +57,18 @@ def make_model(name, device):
     return m, n, dtype
 
 
+def measured_traffic(key, frames_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json, made by
+    tools/summarize_profiles.py on the GPU box: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
+    corrections applied).  Scaled by frames per launch; None if no profile covers this kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(key)
+    return None if k is None else k["hbm_bytes_per_frame"] * frames_per_launch
+
+
 def dominant_roofline(m, x, probs, labels, steps):
     """Untimed profiling pass: per-kernel HIP-event time -> roofline object of the dominant kernel."""
     import torch
@@ -79,12 +91,14 @@ def dominant_roofline(m, x, probs, labels, steps):
         ach = flops / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[m.dtype]
         rl = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-              "frac": ach / peak, "traffic": None, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
+              "frac": ach / peak, "traffic": measured_traffic(f"{name}/{m.dtype}", frames_per_launch),
+              "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
     else:
         by = topo.io_bytes_per_frame * frames_per_launch
         ach = by / (avg_ms * 1e-3) / 1e9
         rl = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
+              "frac": ach / PEAK_HBM_GBS, "traffic": measured_traffic(f"{name}/F{topo.filters}", frames_per_launch),
+              "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
     return rl, kernels
 
 
@@ -129,23 +143,10 @@ def run_workload(name, device, steps, warmup, dist=None):
     x = synthetic_frames(n, seed=2016 + rank, device=f"cuda:{device}")
     probs = torch.empty((n, m.topology.classes), dtype=torch.float32, device=x.device)
     labels = torch.empty((n,), dtype=torch.int32, device=x.device)
-    for _ in range(warmup):
-        m.forward_device(x, probs=probs, labels=labels)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        m.forward_device(x, probs=probs, labels=labels)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=x.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    from modulationdetectioncnn_amd.sharding import timed_region
+    # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps, MAX over ranks
+    el = timed_region(lambda: m.forward_device(x, probs=probs, labels=labels), steps, warmup,
+                      sync=torch.cuda.synchronize, device=x.device)
     return m, x, probs, labels, n, el
 
 

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output under gpurun_out/ into the committed summaries under profiles/.
+
+  kernel stats : gpurun_out/prof_<tag>/runc/*_kernel_stats.csv      -> profiles/<round>_<tag>_kernel_stats.csv
+  HBM traffic  : gpurun_out/pmc_fetch_*/, pmc_write_*/ (separate --pmc passes, as
+                 MI355X_MICROARCH.md "HBM" prescribes) -> profiles/<round>_traffic.json
+Corrections applied (same guide): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so the read side is
+doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def counters(d, kern):
+    fs = glob.glob(os.path.join(G, d, "*", "*_counter_collection.csv"))
+    if not fs:
+        return {}
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if kern in r["Kernel_Name"]:
+            out[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+os.makedirs(P, exist_ok=True)
+for d in sorted(glob.glob(os.path.join(G, "prof_*"))):
+    tag = os.path.basename(d)[5:]
+    for f in glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(P, (tag if tag.startswith(rnd) else f"{rnd}_{tag}") + "_kernel_stats.csv"))
+
+spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in that run)
+    ("mdc_vt_conv/bf16", "vt", "vt_conv_bf16_kernel<0>", 65536),
+    ("mdc_vt_dense1/bf16", "vt", "vt_dense1_bf16", 65536),
+    ("mdc_vt_head", "vt", "vt_head_kernel", 65536),
+    ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3", 1 << 20),
+    ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10", 1 << 20),
+]
+out = {"note": "bytes per launch; FETCH_SIZE doubled (gfx950 wide-read correction), KiB -> bytes", "kernels": {}}
+for key, sfx, kern, frames in spec:
+    fe = counters("pmc_fetch_" + sfx, kern).get("FETCH_SIZE")
+    wr = counters("pmc_write_" + sfx, kern).get("WRITE_SIZE")
+    if fe is None or wr is None:
+        continue
+    rd_b, wr_b = 2.0 * fe * 1024.0, wr * 1024.0
+    out["kernels"][key] = {"frames_per_launch": frames, "FETCH_SIZE_KiB_raw": fe, "WRITE_SIZE_KiB_raw": wr,
+                           "read_bytes": rd_b, "write_bytes": wr_b, "hbm_bytes": rd_b + wr_b,
+                           "hbm_bytes_per_frame": (rd_b + wr_b) / frames}
+json.dump(out, open(os.path.join(P, f"{rnd}_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
