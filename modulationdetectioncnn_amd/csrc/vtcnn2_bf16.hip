@@ -153,23 +153,31 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         // then costs a v_accvgpr_read before the VALU can convert it; the asm form names a VGPR destination.
         // hipcc neither counts wait states for asm nor knows this MFMA's latency: x_fence(h) supplies the
         // XDL-write -> VALU-read wait states before the first pack of row h.
-        auto conv1 = [&](int v, auto par_tag, auto h_tag) {
+        // operand words of row h for conv1 at output index v: pairs i, i+1 (+ i+2 for odd v), i = v>>1.
+        // Loaded one phase BEFORE the conv1 that uses them so the LDS latency is never exposed.
+        unsigned bw[2][3];
+        auto conv1_load = [&](int v, auto par_tag, auto h_tag) {
             constexpr int PAR = decltype(par_tag)::value, h = decltype(h_tag)::value;
             const unsigned* pi = im + (h * kPairs + (v >> 1)) * 64;
+            bw[h][0] = pi[0];
+            bw[h][1] = pi[64];
+            if (PAR == 1) bw[h][2] = pi[128];
+        };
+        auto conv1 = [&](auto par_tag, auto h_tag) {
+            constexpr int PAR = decltype(par_tag)::value, h = decltype(h_tag)::value;
             u32x2 b;
-            if (PAR == 0) {
-                b = u32x2{pi[0], pi[64]};                        // samples v, v+1 | v+2, v+3
-            } else {                                             // odd v: start one sample later
-                const unsigned p0 = pi[0], p1 = pi[64], p2 = pi[128];
-                b = u32x2{__builtin_amdgcn_alignbit(p1, p0, 16), __builtin_amdgcn_alignbit(p2, p1, 16)};
-            }
+            if (PAR == 0) b = u32x2{bw[h][0], bw[h][1]};                       // samples v, v+1 | v+2, v+3
+            else b = u32x2{__builtin_amdgcn_alignbit(bw[h][1], bw[h][0], 16),    // odd v: start one sample later
+                           __builtin_amdgcn_alignbit(bw[h][2], bw[h][1], 16)};
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 f32x4& xd = X[ct][h];            // (asm operands cannot name captured arrays directly)
                 const s16x4& a1 = A1[ct];
-                // "=&v": the result must not share registers with an operand; s_nop 1: a VALU (v_alignbit)
-                // may have written the B operand in the previous cycle (2 wait states, VALU write -> MFMA read)
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xd) : "v"(a1), "v"(b));
+                // "=&v": the result must not share registers with an operand.  s_nop 1 before the first one:
+                // a VALU (v_alignbit) may have written the B operand in the previous cycle (VALU write -> MFMA
+                // read needs 2 wait states and hipcc does not pad asm).
+                if (ct == 0) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xd) : "v"(a1), "v"(b));
+                else asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xd) : "v"(a1), "v"(b));
             }
         };
         auto x_fence = [&](auto h_tag) {
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         auto red_load = [&](auto pb_tag) {
             constexpr int PB = decltype(pb_tag)::value;
             if (ABL == 1) return;
-            __syncthreads();     // s_waitcnt lgkmcnt(0) + s_barrier: every wave's partial(w) is in LDS
+            if (ABL != 6) __syncthreads();     // s_waitcnt lgkmcnt(0) + s_barrier: every wave's partial(w) is in LDS
             const float* pw = part + PB * kPartFloats;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -220,14 +228,23 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         };
         auto red_finish = [&](int w) {
             if (ABL == 1) return;
+            if (ABL == 5) {      // keep the reads live, skip the finishing VALU and the stores
+                for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(rp[k]), "v"(rc[k]));
+                return;
+            }
             const f32x4 s = (rp[0] + rp[1]) + (rp[2] + rp[3]);
             u32x2 o;
             o[0] = pack2relu(s[0] + bq.x, s[1] + bq.y);
             o[1] = pack2relu(s[2] + bq.z, s[3] + bq.w);
             unsigned short* dst = fbase + (long)w * kC2;
-            *reinterpret_cast<u32x2*>(dst + 16 * q) = o;
             const float t = ((rc[0] + rc[1]) + (rc[2] + rc[3])) + b4q;
-            dst[64 + q] = (unsigned short)pack2relu(t, 0.f);
+            const unsigned short t16 = (unsigned short)pack2relu(t, 0.f);
+            if (ABL == 7) {      // keep the values live, skip the global stores
+                asm volatile("" ::"v"(o), "v"(t16));
+                return;
+            }
+            *reinterpret_cast<u32x2*>(dst + 16 * q) = o;
+            dst[64 + q] = t16;
         };
 #define MDC_SB() do { if (ABL != 3) __builtin_amdgcn_sched_barrier(0); } while (0)
         // One position step v (outputs: a0 = v+2 fresh, a1 = v+1, a2 = v completes).  TAP-MAJOR order:
@@ -243,36 +260,37 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         auto step = [&](int v, auto par_next, auto first_tag, auto last_tag, f32x4 (&a0)[5], f32x4 (&a1)[5], f32x4 (&a2)[5]) {
             constexpr bool FIRST = decltype(first_tag)::value != 0, LAST = decltype(last_tag)::value != 0;
             using PB = std::integral_constant<int, 1 - decltype(par_next)::value>;      // = v & 1
-            // R1: tap 2 (20 MFMAs) + pack of row 1 of this step's conv1 (issued late in the previous step)
+            // A: tap 2 (20 MFMAs) + pack of row 1 of this step's conv1 (issued late in the previous step)
             if (!FIRST) { x_fence(I1{}); pack(I1{}, I0{}); pack(I1{}, I1{}); }
+            if (!LAST) conv1_load(v + 1, par_next, I0{});
             tap(I2{}, I0{}, I0{}, a2, false); tap(I2{}, I0{}, I1{}, a2, false);
             tap(I2{}, I1{}, I0{}, a2, false); tap(I2{}, I1{}, I1{}, a2, false);
-            MDC_SB();
-            // R2: the completed output goes to LDS
+            if (ABL == 8) MDC_SB();
+            // B: the completed output goes to LDS while tap 1 (20 MFMAs, writes a1 only) runs; conv1(v+1)
+            //    row 0; finish of output v-1
             part_write(PB{}, a2);
-            MDC_SB();
-            // R3: conv1(v+1) row 0 + tap 1 (20 MFMAs) + finish of output v-1
-            if (!LAST) conv1(v + 1, par_next, I0{});
+            if (!LAST) { conv1(par_next, I0{}); conv1_load(v + 1, par_next, I1{}); }
             tap(I1{}, I0{}, I0{}, a1, false); tap(I1{}, I0{}, I1{}, a1, false);
             if (!FIRST) red_finish(v - 1);
             tap(I1{}, I1{}, I0{}, a1, false); tap(I1{}, I1{}, I1{}, a1, false);
             MDC_SB();
-            // R4: barrier + owner's reads of partial(v)
+            // C: barrier + owner's reads of partial(v) while tap 0 (20 MFMAs, fresh a0 = the registers written
+            //    out one step ago, whose ds_writes completed at the previous barrier) runs; pack of row 0;
+            //    conv1(v+1) row 1
             red_load(PB{});
-            MDC_SB();
-            // R5: tap 0 (20 MFMAs) + pack of row 0 + conv1(v+1) row 1
             tap(I0{}, I0{}, I0{}, a0, true);
             if (!LAST) x_fence(I0{});
             tap(I0{}, I0{}, I1{}, a0, false); if (!LAST) pack(I0{}, I0{});
             tap(I0{}, I1{}, I0{}, a0, false); if (!LAST) pack(I0{}, I1{});
-            if (!LAST) conv1(v + 1, par_next, I1{});
+            if (!LAST) conv1(par_next, I1{});
             tap(I0{}, I1{}, I1{}, a0, false);
             MDC_SB();
         };
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
 
-        conv1(0, P0{}, I0{}); conv1(0, P0{}, I1{});
+        conv1_load(0, P0{}, I0{}); conv1_load(0, P0{}, I1{});
+        conv1(P0{}, I0{}); conv1(P0{}, I1{});
         x_fence(I0{}); x_fence(I1{});
         pack(I0{}, I0{}); pack(I0{}, I1{}); pack(I1{}, I0{}); pack(I1{}, I1{});
         step(0, P1{}, I1{}, I0{}, acc[2], acc[1], acc[0]);
@@ -474,13 +492,18 @@ int vtcnn2_bf16_pack(mdc_model* m) {
 int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-    static const int abl = getenv("MDC_ABLATE") ? atoi(getenv("MDC_ABLATE")) : 0;
 #define MDC_LAUNCH_CONV(A) do { \
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds)); \
     hipLaunchKernelGGL(vt_conv_bf16_kernel<A>, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n, \
                        static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]), \
                        static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat)); } while (0)
-    if (abl == 1) MDC_LAUNCH_CONV(1); else if (abl == 2) MDC_LAUNCH_CONV(2); else if (abl == 3) MDC_LAUNCH_CONV(3); else MDC_LAUNCH_CONV(0);
+#ifdef MDC_ABLATIONS   // timing-only variants for tools/ablate_conv.py (build with -DMDC_ABLATIONS); results are wrong
+    static const int abl = getenv("MDC_ABLATE") ? atoi(getenv("MDC_ABLATE")) : 0;
+    switch (abl) { case 1: MDC_LAUNCH_CONV(1); break; case 2: MDC_LAUNCH_CONV(2); break; case 3: MDC_LAUNCH_CONV(3); break; case 5: MDC_LAUNCH_CONV(5); break;
+                  case 6: MDC_LAUNCH_CONV(6); break; case 7: MDC_LAUNCH_CONV(7); break; case 8: MDC_LAUNCH_CONV(8); break; default: MDC_LAUNCH_CONV(0); }
+#else
+    MDC_LAUNCH_CONV(0);
+#endif
 #undef MDC_LAUNCH_CONV
     MDC_HIP(hipGetLastError());
     return MDC_OK;

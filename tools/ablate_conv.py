@@ -2,7 +2,10 @@
 """Timing-only ablations of the bf16 conv kernel (MDC_ABLATE=1: no exchange/barrier/store,
 2: no conv1+pack).  Results are wrong by construction; only the kernel time is read."""
 import os, subprocess, sys, json
-for abl in ("0", "1", "2"):
+sys.path.insert(0, ".")
+from modulationdetectioncnn_amd import build as _b
+_b.build(force=True, extra_flags=["-DMDC_ABLATIONS"])   # NOTE: rebuild without the flag afterwards
+for abl in (sys.argv[1:] or ["0", "1", "2"]):
     env = dict(os.environ, MDC_ABLATE=abl)
     r = subprocess.run([sys.executable, "bench.py", "--no-extras", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"],
                        env=env, capture_output=True, text=True)
