@@ -46,7 +46,7 @@ enum {
                                F = filters in {3,10}, C = 3.  Layers: 0 conv, 1 dense.             */
     MDC_KIND_VTCNN2   = 2,  /* RML2016.10a_VTCNN2_example.ipynb:229-243: pad(0,2) Conv(256,1x3) relu
                                pad(0,2) Conv(80,2x3) relu Flatten Dense(256,relu) Dense(C) softmax.
-                               Layers: 0 conv1, 1 conv2, 2 dense1, 3 dense2.  C <= 32.             */
+                               Layers: 0 conv1, 1 conv2, 2 dense1, 3 dense2.  C <= 16.             */
     MDC_KIND_CNNPY    = 3   /* cnn.py:104-115 literal model (H=1,W=2,C=128 under channels_last):
                                pad(0,1) Conv2D(F,(1,2)) relu Flatten Dense(D,relu) Dense(C) softmax.
                                Layers: 0 conv, 1 dense1, 2 dense2.                                 */

@@ -1,0 +1,200 @@
+// dense_chain: rows of 256 f32 -> [Dense(N1) (ReLU?)] -> [Dense(N2) (ReLU?)] -> [Dense(N3)] -> softmax ->
+// first-max argmax, on 16-row tiles with v_mfma_f32_16x16x4_f32 (exact f32 fma chains).
+//
+// Two users:
+//  * the VT-CNN2 head (one layer, 256 -> C): Dense(C) + softmax + np.argmax of
+//    RML2016.10a_VTCNN2_example.ipynb:241-243 / cnn.py:209;
+//  * the literal cnn.py model (cnn.py:104-115): under TensorFlow's channels_last
+//    `Reshape([1,2,128])` is H=1, W=2, C=128, so pad(0,1)+Conv2D(F,(1,2)) is a LINEAR map of the 256
+//    input floats to 3F outputs.  It is folded into a dense 256 x 3F matrix at pack time, followed by
+//    ReLU, Dense(D, relu), Dense(C), softmax: three layers of this kernel, input = the raw frame.
+//
+// One wave = one 16-row tile at a time.  The 16 KiB of input rows are loaded with coalesced 16-B
+// loads, staged in LDS, and read back as MFMA A operands (A[row][k]); every layer's weights sit in
+// registers as B operands (B[k][col]); a layer's 16x16 result (col on the lane) goes through a
+// 2 KiB LDS transpose to become the next layer's A operand.  HBM-bound: 1 KiB read per row.
+#include "mdc_internal.h"
+
+#include <cmath>
+
+namespace mdc {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+namespace {
+
+constexpr int kK0 = 256;          // input width (floats per row)
+constexpr int kXld = 260;         // LDS row stride of the staged input (16-B aligned rows)
+constexpr int kYld = 36;          // LDS row stride of an inter-layer activation tile (<= 32 columns)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// butterfly over the 16 lanes of a DPP row: afterwards every lane holds op over the row
+template <typename Op>
+__device__ __forceinline__ float row_allreduce(float v, Op op) {
+    v = op(v, dpp_mov<0xB1>(v));     // quad_perm [1,0,3,2]
+    v = op(v, dpp_mov<0x4E>(v));     // quad_perm [2,3,0,1]
+    v = op(v, dpp_mov<0x141>(v));    // row_half_mirror
+    v = op(v, dpp_mov<0x140>(v));    // row_mirror
+    return v;
+}
+
+struct ChainParams {
+    const float* x;        // [n][256]
+    long n;
+    const float* w;        // packed: layer 1 [T1][64 ksteps][64 lanes]; layer 2 [8][64]; layer 3 [8][64]; biases [3][32]
+    int nl;                // number of layers (1 or 3)
+    int n_out;             // classes C (columns of the last layer)
+    int relu1, relu2;      // ReLU after layer 1 / 2
+    float* probs;
+    int* labels;
+    float* tap_logits;     // last layer pre-softmax (or NULL)
+    float* tap_h1;         // layer-1 output after its activation, [n][n1] (or NULL)
+    float* tap_h2;         // layer-2 output after its activation, [n][n2] (or NULL)
+    int n1, n2;            // real widths of layers 1, 2 (for the taps)
+};
+
+template <int T1, int NL>
+__global__ __launch_bounds__(256) void dense_chain_kernel(ChainParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    float* xs = smem + wv * (16 * kXld + 16 * kYld);
+    float* ys = xs + 16 * kXld;
+
+    // ---- weights into registers (B operands: lane (col = fr, k-group g) holds W[4i + g][col]) ----
+    float w1[T1][64];
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) w1[t][i] = p.w[(t * 64 + i) * 64 + lane];
+    const float* wp2 = p.w + T1 * 64 * 64;
+    float w2[8], w3[8];
+    if (NL == 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w2[i] = wp2[i * 64 + lane]; w3[i] = wp2[(8 + i) * 64 + lane]; }
+    }
+    const float* bias = wp2 + 16 * 64;
+    float b1[T1];
+#pragma unroll
+    for (int t = 0; t < T1; ++t) b1[t] = bias[t * 16 + fr];
+    const float b2 = bias[32 + fr], b3 = bias[64 + fr];
+
+    const long ntiles = (p.n + 15) >> 4;
+    const long nwaves = (long)gridDim.x * 4;
+    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += nwaves) {
+        const long row0 = tile << 4;
+        // ---- stage 16 rows (1 KiB each): one coalesced float4 per lane per row ----
+        float4 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < p.n) v[r] = reinterpret_cast<const float4*>(p.x + (row0 + r) * kK0)[lane];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *reinterpret_cast<float4*>(xs + r * kXld + 4 * lane) = v[r];
+        // (single wave: LDS ordering within the wave needs no barrier, only the waits hipcc inserts)
+
+        // ---- layer 1: K = 256 ----
+        f32x4 acc[T1];
+#pragma unroll
+        for (int t = 0; t < T1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float a = xs[fr * kXld + 4 * i + g];
+#pragma unroll
+            for (int t = 0; t < T1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w1[t][i], acc[t], 0, 0, 0);
+        }
+        f32x4 z;      // final-layer pre-softmax values: lane (class = fr), rows 4g + r
+        if (NL == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = acc[0][r] + b1[0];
+        } else {
+            // activation, transpose through LDS: ys[row][col]
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float h = acc[t][r] + b1[t];
+                    if (p.relu1) h = fmaxf(h, 0.f);
+                    ys[(4 * g + r) * kYld + t * 16 + fr] = h;
+                    if (p.tap_h1 && t * 16 + fr < p.n1 && row0 + 4 * g + r < p.n) p.tap_h1[(row0 + 4 * g + r) * p.n1 + t * 16 + fr] = h;
+                }
+            // ---- layer 2: K <= 32 ----
+            f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kYld + 4 * i + g], w2[i], a2, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h = a2[r] + b2;
+                if (p.relu2) h = fmaxf(h, 0.f);
+                a2[r] = h;
+                if (p.tap_h2 && fr < p.n2 && row0 + 4 * g + r < p.n) p.tap_h2[(row0 + 4 * g + r) * p.n2 + fr] = h;
+            }
+            // the layer-3 A operand reads ys after every lane's layer-2 reads are done (same wave, in order)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ys[(4 * g + r) * kYld + fr] = a2[r];
+            // ---- layer 3: K <= 16 ----
+            f32x4 a3 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kYld + 4 * i + g], w3[i], a3, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = a3[r] + b3;
+        }
+        // ---- softmax + first-max argmax over the classes (the 16 lanes of a DPP row) ----
+        const bool cls = fr < p.n_out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = row0 + 4 * g + r;
+            const float zz = cls ? z[r] : -INFINITY;
+            const float mx = row_allreduce(zz, [](float a, float b) { return fmaxf(a, b); });
+            const float e = cls ? expf(zz - mx) : 0.f;
+            const float sum = row_allreduce(e, [](float a, float b) { return a + b; });
+            // np.argmax: FIRST index attaining the maximum (cnn.py:209)
+            const float cand = (zz == mx) ? (float)fr : 1e9f;
+            const float arg = row_allreduce(cand, [](float a, float b) { return fminf(a, b); });
+            if (row < p.n) {
+                if (cls) {
+                    if (p.probs) p.probs[row * p.n_out + fr] = e / sum;
+                    if (p.tap_logits) p.tap_logits[row * p.n_out + fr] = z[r];
+                }
+                if (fr == 0 && p.labels) p.labels[row] = (int)arg;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Host-side packing of one layer's (in, out) kernel into B-operand order [kstep][lane]:
+// lane (col = lane&15, g = lane>>4) of k-step i holds W[4i + g][tile*16 + col] (0 outside the matrix).
+void chain_pack_layer(std::vector<float>& dst, const float* w, int k_in, int n_out, int ksteps, int tiles) {
+    for (int t = 0; t < tiles; ++t)
+        for (int i = 0; i < ksteps; ++i)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = 4 * i + (lane >> 4), c = t * 16 + (lane & 15);
+                dst.push_back((k < k_in && c < n_out) ? w[(size_t)k * n_out + c] : 0.f);
+            }
+}
+
+int chain_launch(int t1, int nl, const float* x, long n, const float* wpack, int n_out, int relu1, int relu2,
+                 float* probs, int* labels, float* tap_logits, float* tap_h1, float* tap_h2, int n1, int n2, hipStream_t s) {
+    ChainParams p{x, n, wpack, nl, n_out, relu1, relu2, probs, labels, tap_logits, tap_h1, tap_h2, n1, n2};
+    const long ntiles = (n + 15) / 16;
+    long grid = (ntiles + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    const size_t lds = (size_t)4 * (16 * kXld + 16 * kYld) * sizeof(float);    // 75,776 B
+    const void* fn = nullptr;
+    if (t1 == 1 && nl == 1) fn = reinterpret_cast<const void*>(dense_chain_kernel<1, 1>);
+    else if (t1 == 2 && nl == 3) fn = reinterpret_cast<const void*>(dense_chain_kernel<2, 3>);
+    else { set_error("dense_chain: unsupported shape (t1=%d, layers=%d)", t1, nl); return MDC_ENOTSUP; }
+    MDC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (t1 == 1) hipLaunchKernelGGL((dense_chain_kernel<1, 1>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((dense_chain_kernel<2, 3>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    MDC_HIP(hipGetLastError());
+    return MDC_OK;
+}
+
+}  // namespace mdc

@@ -66,7 +66,7 @@ static int layer_layout(mdc_model* m) {
             m->slots = {{"mdc_deployed_fwd"}};
             return MDC_OK;
         case MDC_KIND_VTCNN2:
-            if (t.classes < 2 || t.classes > 32) { set_error("vtcnn2: classes must be in 2..32 (got %d)", t.classes); return MDC_ENOTSUP; }
+            if (t.classes < 2 || t.classes > 16) { set_error("vtcnn2: classes must be in 2..16 (got %d)", t.classes); return MDC_ENOTSUP; }
             m->nlayers = 4;
             m->nk[0] = (size_t)kC1 * 3;               m->nb[0] = kC1;
             m->nk[1] = (size_t)kC2 * kC1 * 2 * 3;     m->nb[1] = kC2;
@@ -75,15 +75,15 @@ static int layer_layout(mdc_model* m) {
             m->slots = {{"mdc_vt_conv"}, {"mdc_vt_dense1"}, {"mdc_vt_head"}};
             return MDC_OK;
         case MDC_KIND_CNNPY:
-            if (t.filters < 1 || t.filters > 16 || t.hidden < 1 || t.hidden > 32 || t.classes < 2 || t.classes > 16) {
-                set_error("cnnpy: need filters 1..16, hidden 1..32, classes 2..16 (got %d,%d,%d)", t.filters, t.hidden, t.classes);
+            if (t.filters < 1 || t.filters > 10 || t.hidden < 1 || t.hidden > 16 || t.classes < 2 || t.classes > 16) {
+                set_error("cnnpy: need filters 1..10, hidden 1..16, classes 2..16 (got %d,%d,%d)", t.filters, t.hidden, t.classes);
                 return MDC_ENOTSUP;
             }
             m->nlayers = 3;
             m->nk[0] = 2 * 128 * (size_t)t.filters;        m->nb[0] = t.filters;
             m->nk[1] = 3 * (size_t)t.filters * t.hidden;    m->nb[1] = t.hidden;
             m->nk[2] = (size_t)t.hidden * t.classes;        m->nb[2] = t.classes;
-            m->slots = {{"mdc_cnnpy_fwd"}};
+            m->slots = {{"mdc_dense_chain"}};
             return MDC_OK;
         default:
             set_error("unknown topology kind %d", t.kind);

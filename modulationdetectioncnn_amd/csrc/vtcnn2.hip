@@ -232,73 +232,6 @@ __global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restr
         }
 }
 
-// ------------------------------------------------------------------------------------
-// head: logits = hid W2 + c2; softmax; first-max argmax (cnn.py:209).  64 frames per block,
-// 4 threads per frame (each 64 of the 256 hidden units), combined through LDS.
-// ------------------------------------------------------------------------------------
-constexpr int kMaxC = 32;
-
-__global__ __launch_bounds__(256) void vt_head_kernel(const float* __restrict__ hid, long n, int C,
-                                                      const float* __restrict__ w2,   // [256][C]
-                                                      const float* __restrict__ c2,   // [C]
-                                                      float* __restrict__ probs, int* __restrict__ labels,
-                                                      float* __restrict__ tap_logits) {
-    __shared__ float Ws[kHid * kMaxC];
-    __shared__ float part[4][64][kMaxC + 1];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < kHid * C; i += 256) Ws[i] = w2[i];
-    const int fl = tid & 63, kq = tid >> 6;
-    const long f = (long)blockIdx.x * 64 + fl;
-    float s[kMaxC];
-#pragma unroll
-    for (int c = 0; c < kMaxC; ++c) s[c] = 0.f;
-    __syncthreads();
-    if (f < n) {
-        const float4* hp = reinterpret_cast<const float4*>(hid + f * kHid + kq * 64);
-        for (int k4 = 0; k4 < 16; ++k4) {
-            const float4 hv = hp[k4];
-            const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float* wrow = Ws + (kq * 64 + k4 * 4 + e) * C;
-#pragma unroll
-                for (int c = 0; c < kMaxC; ++c)
-                    if (c < C) s[c] = fmaf(hh[e], wrow[c], s[c]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < kMaxC; ++c)
-        if (c < C) part[kq][fl][c] = s[c];
-    __syncthreads();
-    if (kq == 0 && f < n) {
-        float z[kMaxC];
-        float mx = -INFINITY;
-        int arg = 0;
-#pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
-            if (c < C) {
-                z[c] = ((part[0][fl][c] + part[1][fl][c]) + (part[2][fl][c] + part[3][fl][c])) + c2[c];
-                if (z[c] > mx) { mx = z[c]; arg = c; }     // strict '>' keeps the FIRST maximum
-            }
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
-            if (c < C) { z[c] = expf(z[c] - mx); sum += z[c]; }
-        const float inv = 1.0f / sum;
-        if (labels) labels[f] = arg;
-#pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
-            if (c < C) {
-                if (probs) probs[f * C + c] = z[c] * inv;
-            }
-    }
-    if (tap_logits && kq == 1 && f < n) {
-        for (int c = 0; c < C; ++c)
-            tap_logits[f * C + c] = ((part[0][fl][c] + part[1][fl][c]) + (part[2][fl][c] + part[3][fl][c])) + c2[c];
-    }
-}
-
 // feat[f][w][o] (f32 or bf16) -> reference layout (80,132) channels_first, f32   ('conv'/'flat' taps)
 template <typename T>
 __global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* __restrict__ out) {
@@ -314,13 +247,18 @@ __global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* _
 
 }  // namespace
 
+// ---- dense_chain.hip: Dense(C) + softmax + first-max argmax of the head -----------------
+void chain_pack_layer(std::vector<float>& dst, const float* w, int k_in, int n_out, int ksteps, int tiles);
+int chain_launch(int t1, int nl, const float* x, long n, const float* wpack, int n_out, int relu1, int relu2,
+                 float* probs, int* labels, float* tap_logits, float* tap_h1, float* tap_h2, int n1, int n2, hipStream_t s);
+
 // ---- bf16 entry points (vtcnn2_bf16.hip) ------------------------------------------------
 int vtcnn2_bf16_pack(mdc_model* m);
 int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
 int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s);
 
 // d_pack slots: 0 conv2 weights, 1 conv1 operand, 2 conv2 bias, 3 dense1 weights (permuted),
-//               4 dense1 bias, 5 dense2 weights, 6 dense2 bias
+//               4 dense1 bias, 5 head (dense2) pack for dense_chain
 int vtcnn2_pack(mdc_model* m) {
     const float* k1 = m->hk[0].data();   // OIHW (256,1,1,3)
     const float* b1 = m->hb[0].data();
@@ -328,8 +266,17 @@ int vtcnn2_pack(mdc_model* m) {
     int rc;
     if ((rc = upload(m, 2, m->hb[1].data(), kC2 * sizeof(float)))) return rc;
     if ((rc = upload(m, 4, m->hb[2].data(), kHid * sizeof(float)))) return rc;
-    if ((rc = upload(m, 5, m->hk[3].data(), m->hk[3].size() * sizeof(float)))) return rc;
-    if ((rc = upload(m, 6, m->hb[3].data(), m->hb[3].size() * sizeof(float)))) return rc;
+    {   // head: dense2 as the single layer of the dense_chain kernel
+        const int C = m->topo.classes;
+        if (C > 16) { set_error("vtcnn2: the HIP head covers up to 16 classes (got %d)", C); return MDC_ENOTSUP; }
+        std::vector<float> pk;
+        chain_pack_layer(pk, m->hk[3].data(), kHid, C, 64, 1);
+        pk.resize(pk.size() + 16 * 64, 0.f);                 // layers 2/3 unused
+        std::vector<float> bias(96, 0.f);
+        for (int c = 0; c < C; ++c) bias[c] = m->hb[3][c];
+        pk.insert(pk.end(), bias.begin(), bias.end());
+        if ((rc = upload(m, 5, pk.data(), pk.size() * sizeof(float)))) return rc;
+    }
     if (m->dtype == MDC_BF16) return vtcnn2_bf16_pack(m);
 
     // conv2 weights: [chunk][h][j][ot][r][lane] = K2[16ot + (lane&15)][16chunk + 4(lane>>4) + r][h][j]
@@ -406,10 +353,9 @@ int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, 
     }
     {
         ProfScope ps(m, 2, s);
-        hipLaunchKernelGGL(vt_head_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, hid, (long)n, C,
-                           static_cast<const float*>(m->d_pack[5]), static_cast<const float*>(m->d_pack[6]), probs, labels,
-                           tap_kind == MDC_TAP_DENSE ? tap : nullptr);
-        MDC_HIP(hipGetLastError());
+        if ((rc = chain_launch(1, 1, hid, (long)n, static_cast<const float*>(m->d_pack[5]), C, 0, 0, probs, labels,
+                               tap_kind == MDC_TAP_DENSE ? tap : nullptr, nullptr, nullptr, 0, 0, s)))
+            return rc;
     }
     if (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) {
         const long total = (long)n * kFeat;
