@@ -18,6 +18,8 @@
 // HBM traffic = the algorithmic 1,036 B/frame (1,024 in + 12 out) + 4 B label.
 #include "mdc_internal.h"
 
+#include <cstdlib>
+
 namespace mdc {
 
 namespace {
@@ -44,8 +46,9 @@ __device__ __forceinline__ float wave_total(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Simple one-frame-at-a-time variant: used only when a conv/flat tap is requested (slow path).
 template <int F, int TAP>   // TAP: 0 none, 1 conv/flat (model4/model3), 2 dense (model2)
-__global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restrict__ x, long n,
+__global__ __launch_bounds__(256) void deployed_tap_kernel(const float* __restrict__ x, long n,
                                                            const float* __restrict__ wp,
                                                            float* __restrict__ probs, int* __restrict__ labels,
                                                            float* __restrict__ tap_conv, float* __restrict__ tap_dense) {
@@ -138,6 +141,190 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path.  Same lane mapping, but (a) frames are processed four at a time and their 12 partial
+// sums are reduced with a bank-masked DPP reduce-scatter (each 4-lane bank ends up owning one frame:
+// 12+12 adds for the two bank levels, 6 inside the bank, 2 permlane swaps per class across the four
+// 16-lane rows) instead of a full 6-step wave reduction per value; (b) the 129th conv position
+// (w = 0), which only one lane per row owns, is not a fifth slot any more: the position is evaluated once per 64-frame
+// block for all frames at once, with scalar weights (x[h][0] is re-read by the finishing lane: an L2 hit).
+// Result lane of frame j = 4G + f of the block:  16*(G>>2) + 4*bank(f) + (G&3),  bank = {0,2,1,3}[f].
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_add_banks(float v) {
+    // v + (v moved by CTRL) in the banks selected by BANK_MASK; other banks unchanged
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, BANK_MASK, true);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float rows_sum(float m) {       // sum over the four 16-lane rows, result in all rows
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// TAIL = true: the same arithmetic (bit-identical results, so predict() does not depend on how a batch is
+// chunked) on ONE ragged block of n < 64 frames with guarded loads and stores.
+template <int F, int TAP, int ABL = 0, bool TAIL = false>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
+__global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restrict__ x, long n,
+                                                           const float* __restrict__ wp,
+                                                           float* __restrict__ probs, int* __restrict__ labels,
+                                                           float* __restrict__ tap_dense) {
+    const int lane = threadIdx.x & 63;
+    const int lp = lane & 31;
+
+    float k0[F], k1[F], cb[F], bd[kC];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        k0[f] = wp[3 * f + 0];
+        k1[f] = wp[3 * f + 1];
+        cb[f] = wp[3 * f + 2];
+    }
+#pragma unroll
+    for (int c = 0; c < kC; ++c) bd[c] = wp[3 * F + c];
+    float wd[4][F][kC];      // dense weights of this lane's own four positions
+    {
+        const float* wl = wp + kHeadFloats + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int c = 0; c < kC; ++c) wd[s][f][c] = wl[((s * F + f) * kC + c) * 64];
+    }
+    // dense weights of position w = 0 of row 0 / row 1 (wave-uniform): slot 4 of lanes 0 and 32
+    const float* we0 = wp + kHeadFloats + (4 * F * kC) * 64;
+    // lane -> block-relative frame it finishes
+    const int myG = 4 * (lane >> 4) + (lane & 3);
+    const int myb = (lane >> 2) & 3;
+    const int myframe = 4 * myG + ((myb == 1) ? 2 : (myb == 2) ? 1 : myb);
+
+    // FULL 64-frame blocks only (the host launches the one-frame-at-a-time kernel on a ragged tail), so
+    // every load is unconditional: guarded loads made hipcc wait for the prefetch right after issuing it.
+    const long nwaves = (long)gridDim.x * 4;
+    const long nblk = TAIL ? 1 : (n >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (long blk = (long)blockIdx.x * 4 + wv; blk < nblk; blk += nwaves) {
+        const long base = blk << 6;
+        float r[kC] = {0.f, 0.f, 0.f};
+        // x[0][0] / x[1][0] of the frame this lane finishes: two 4-byte gathers per 64-frame block, issued now and
+        // consumed after the last group (the lines are the ones the streaming loads below fetch anyway)
+        float eI = 0.f, eQ = 0.f;
+        if (!(ABL & 1) && (!TAIL || myframe < n)) {
+            const float* pe = x + (base + myframe) * kFrameFloats;
+            eI = pe[0];
+            eQ = pe[kSamples];
+        }
+        const float4* px = reinterpret_cast<const float4*>(x + base * kFrameFloats) + lane;
+        float4 cur[4], nx[4];
+        auto load = [&](int j) {
+            if (!TAIL) return px[(long)j * 64];
+            return (j < n) ? px[(long)j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+#pragma unroll
+        for (int f = 0; f < 4; ++f) cur[f] = load(f);
+        for (int G = 0; G < 16; ++G) {
+            // prefetch the next group (the last group re-reads itself: harmless, stays in bounds).  One group
+            // ahead is the measured optimum; two groups ahead (12 KB per wave in flight) was 10 % slower.
+            const int Gn = (G < 15) ? G + 1 : 15;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) nx[f] = load(4 * Gn + f);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the group
+            float v[4][kC];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                // sample x[4l'+4]: first sample of the next lane; right zero-pad at the row end
+                float nxt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cur[f].x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+                nxt = (lp == 31) ? 0.f : nxt;
+                const float xs[5] = {cur[f].x, cur[f].y, cur[f].z, cur[f].w, nxt};
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                if (ABL & 4) { s0 = xs[0] + xs[1]; s1 = xs[2] + xs[3]; s2 = xs[4]; }     // memory-only probe
+                else
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ff = 0; ff < F; ++ff) {
+                        float y = fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff]));
+                        y = fmaxf(y, 0.f);
+                        s0 = fmaf(wd[s][ff][0], y, s0);
+                        s1 = fmaf(wd[s][ff][1], y, s1);
+                        s2 = fmaf(wd[s][ff][2], y, s2);
+                    }
+                v[f][0] = s0; v[f][1] = s1; v[f][2] = s2;
+            }
+            // ---- reduce-scatter with fused, bank-masked DPP adds (one instruction each; lanes outside the
+            // bank mask keep their value).  Level 1: banks {0,2} take frames 0,1 from lane+4, banks {1,3} take
+            // frames 2,3 from lane-4.  Level 2 writes ONE register per class: bank 0 <- frame 0 (+ lane+8),
+            // bank 2 <- frame 1 (+ lane-8), bank 1 <- frame 2 (+ lane+8), bank 3 <- frame 3 (+ lane-8).
+            // All ops of a level are issued before the next level, so no DPP reads a register written by the
+            // instruction just before it (hipcc does not pad asm with the 2 wait states that would need).
+            float m[kC];
+            if (ABL & 2) {
+#pragma unroll
+                for (int c = 0; c < kC; ++c) m[c] = (v[0][c] + v[1][c]) + (v[2][c] + v[3][c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < kC; ++c) {
+                    asm volatile("v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(v[0][c]));
+                    asm volatile("v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(v[1][c]));
+                    asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(v[2][c]));
+                    asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(v[3][c]));
+                }
+#pragma unroll
+                for (int c = 0; c < kC; ++c) {
+                    m[c] = 0.f;
+                    asm volatile("v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x1" : "+v"(m[c]) : "v"(v[0][c]));
+                    asm volatile("v_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0x4" : "+v"(m[c]) : "v"(v[1][c]));
+                    asm volatile("v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x2" : "+v"(m[c]) : "v"(v[2][c]));
+                    asm volatile("v_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0x8" : "+v"(m[c]) : "v"(v[3][c]));
+                }
+#pragma unroll
+                for (int c = 0; c < kC; ++c) {
+                    float t = m[c];
+                    t = dpp_add<0xB1, 0xf>(t);                           // inside the bank: quad_perm [1,0,3,2]
+                    t = dpp_add<0x4E, 0xf>(t);                           //                  quad_perm [2,3,0,1]
+                    m[c] = rows_sum(t);
+                }
+            }
+            if (myG == G) { r[0] = m[0]; r[1] = m[1]; r[2] = m[2]; }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) cur[f] = nx[f];
+        }
+        // ---- position w = 0 of both rows, all 64 frames at once: y = relu(b + K1*x[h][0]) (x[h][-1] = 0)
+#pragma unroll
+        for (int ff = 0; ff < F; ++ff) {
+            const float yI = fmaxf(fmaf(k1[ff], eI, cb[ff]), 0.f);
+            const float yQ = fmaxf(fmaf(k1[ff], eQ, cb[ff]), 0.f);
+#pragma unroll
+            for (int c = 0; c < kC; ++c) {
+                r[c] = fmaf(we0[(ff * kC + c) * 64 + 0], yI, r[c]);
+                r[c] = fmaf(we0[(ff * kC + c) * 64 + 32], yQ, r[c]);
+            }
+        }
+        const long o = base + myframe;
+        if (!TAIL || o < n) {
+            const float z0 = fmaxf(r[0] + bd[0], 0.f);   // Dense(3, activation='relu')
+            const float z1 = fmaxf(r[1] + bd[1], 0.f);
+            const float z2 = fmaxf(r[2] + bd[2], 0.f);
+            const float mx = fmaxf(z0, fmaxf(z1, z2));
+            const float e0 = expf(z0 - mx), e1 = expf(z1 - mx), e2 = expf(z2 - mx);
+            const float inv = 1.0f / (e0 + e1 + e2);
+            if (probs) {
+                probs[o * 3 + 0] = e0 * inv;
+                probs[o * 3 + 1] = e1 * inv;
+                probs[o * 3 + 2] = e2 * inv;
+            }
+            // np.argmax: first maximum (equal z give bit-equal e, so argmax z == argmax p, ties included)
+            if (labels) labels[o] = (z0 >= z1 && z0 >= z2) ? 0 : ((z1 >= z2) ? 1 : 2);
+            if (TAP == 2) {
+                tap_dense[o * 3 + 0] = z0;
+                tap_dense[o * 3 + 1] = z1;
+                tap_dense[o * 3 + 2] = z2;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Pack: [F x (k0,k1,b)] [bd x3] pad to 64 floats, then per-lane dense weights
@@ -172,22 +359,48 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
                      float* tap, int tap_kind, hipStream_t s) {
     if (tap_kind == MDC_TAP_HIDDEN) { set_error("deployed nets have no hidden dense layer to tap"); return MDC_EINVAL; }
     const float* wp = static_cast<const float*>(m->d_pack[0]);
-    const long nblk = (n + 63) / 64;
-    long grid = (nblk + 3) / 4;
-    if (grid > 2048) grid = 2048;
     const int F = m->topo.filters;
     float* tap_conv = (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) ? tap : nullptr;
     float* tap_dense = (tap_kind == MDC_TAP_DENSE) ? tap : nullptr;
+    const long nfull = tap_conv ? 0 : (n / 64) * 64;      // frames handled by the fast kernel
     ProfScope ps(m, 0, s);
-#define MDC_LAUNCH_DEPLOYED(FF, TT) \
-    hipLaunchKernelGGL((deployed_fwd_kernel<FF, TT>), dim3(grid), dim3(256), 0, s, x, (long)n, wp, probs, labels, tap_conv, tap_dense)
-    const int tt = tap_conv ? 1 : (tap_dense ? 2 : 0);
-    if (F == 3) {
-        if (tt == 0) MDC_LAUNCH_DEPLOYED(3, 0); else if (tt == 1) MDC_LAUNCH_DEPLOYED(3, 1); else MDC_LAUNCH_DEPLOYED(3, 2);
-    } else {
-        if (tt == 0) MDC_LAUNCH_DEPLOYED(10, 0); else if (tt == 1) MDC_LAUNCH_DEPLOYED(10, 1); else MDC_LAUNCH_DEPLOYED(10, 2);
+    if (nfull > 0) {
+        long grid = (nfull / 64 + 3) / 4;
+        if (grid > 2048) grid = 2048;
+#ifdef MDC_ABLATIONS
+        static const int abl = getenv("MDC_ABLATE_DEP") ? atoi(getenv("MDC_ABLATE_DEP")) : 0;
+        if (abl == 1 && F == 3) { hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 1>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); return MDC_OK; }
+        if (abl == 2 && F == 3) { hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); return MDC_OK; }
+        if (abl == 3 && F == 3) { hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 3>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); return MDC_OK; }
+        if (abl == 7 && F == 3) { hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 7>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); return MDC_OK; }
+#endif
+        if (tap_dense) {
+            if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
+            else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
+        } else {
+            if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
+            else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
+        }
     }
-#undef MDC_LAUNCH_DEPLOYED
+    if (nfull < n) {        // ragged tail (< 64 frames) or a conv tap: the simple kernel
+        const long nt = n - nfull;
+        const float* xt = x + nfull * kFrameFloats;
+        float* pt = probs ? probs + nfull * 3 : nullptr;
+        int* lt = labels ? labels + nfull : nullptr;
+        float* tc = tap_conv;                               // (tap_conv implies nfull == 0)
+        float* td = tap_dense ? tap_dense + nfull * 3 : nullptr;
+        if (tc) {       // conv/flat tap: the one-frame-at-a-time kernel over the whole batch
+            const long g2 = ((nt + 63) / 64 + 3) / 4 > 2048 ? 2048 : ((nt + 63) / 64 + 3) / 4;
+            if (F == 3) hipLaunchKernelGGL((deployed_tap_kernel<3, 1>), dim3((unsigned)g2), dim3(256), 0, s, xt, nt, wp, pt, lt, tc, td);
+            else        hipLaunchKernelGGL((deployed_tap_kernel<10, 1>), dim3((unsigned)g2), dim3(256), 0, s, xt, nt, wp, pt, lt, tc, td);
+        } else if (td) {
+            if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 2, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
+            else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 2, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
+        } else {
+            if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
+            else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
+        }
+    }
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }
