@@ -43,7 +43,7 @@ namespace {
 constexpr int kPairs = 66;                        // 132 padded samples per row, as bf16 pairs
 constexpr int kImgWords = 2 * kPairs * 64;        // [row h][pair][lane]  u32
 constexpr int kPartFloats = 4 * 5 * 64 * 4;       // [wave][ot][lane][4]  f32
-constexpr size_t kConvBf16Lds = (size_t)2 * kImgWords * 4 + (size_t)2 * kPartFloats * 4;   // 108,544 B
+constexpr size_t kConvBf16Lds = (size_t)2 * kImgWords * 4 + (size_t)2 * kPartFloats * 4 + 512;   // 109,056 B (+ conv2 bias)
 constexpr int kWFrags = 2 * 3 * 2 * 5;            // [h][j][cp][ot] = 60 fragments per wave
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {          // two f32 -> packed bf16 (RNE)
@@ -111,11 +111,12 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
     s16x4 A1[4];          // taps at k-slots 0..2 (even positions); odd positions shift the B operand instead
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) A1[ct] = __builtin_bit_cast(s16x4, a1q[(q * 4 + ct) * 64 + lane]);
-    float4 bq = *reinterpret_cast<const float4*>(b2 + 16 * q + 4 * g);     // this wave reduces output tile q ...
-    float b4q = b2[64 + 4 * g + q];                                         // ... and component q of tile 4
-    // consume the loads here: otherwise their first use inside the main loop carries an s_waitcnt vmcnt(N)
-    // that also waits for the previous steps' feature STORES (vmcnt is in-order) on every iteration
-    asm volatile("" : "+v"(bq.x), "+v"(bq.y), "+v"(bq.z), "+v"(bq.w), "+v"(b4q));
+    // conv2 bias: kept in LDS and read where it is used (it would cost 5 persistent registers in a kernel that
+    // sits exactly at the register limit); this wave finishes output tile q and component q of tile 4
+    float* bias_lds = part + 2 * kPartFloats;
+    if (tid < kC2) bias_lds[tid] = b2[tid];
+    const float* bq_lds = bias_lds + 16 * q + 4 * g;
+    const float* b4_lds = bias_lds + 64 + 4 * g + q;
 
     // ---- LDS init: zero padding pairs and the constant bias-slot lanes, both buffers ----
     for (int i = tid; i < 2 * kImgWords; i += 256) img[i] = ((i & 63) >= 48) ? 0x3F803F80u : 0u;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 Bf[2][2];
+        bf16x8 Bf[2][2][2];   // [step parity][row][channel pair]: the pack for step v+1 never overwrites operands of step v
         f32x4 X[4][2];        // conv1 tiles [channel tile][row]; row 0 and row 1 are live at different times
         f32x4 rp[4];
         float rc[4];
@@ -186,20 +187,24 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
             asm volatile("s_nop 7\n\ts_nop 7" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
         };
         // ReLU + bf16 of the conv1 tile pair (row h, channel pair cp): already a B operand
-        auto pack = [&](auto h_tag, auto cp_tag) {
-            constexpr int h = decltype(h_tag)::value, cp = decltype(cp_tag)::value;
+        auto pack = [&](auto sp_tag, auto h_tag, auto cp_tag) {
+            constexpr int sp = decltype(sp_tag)::value, h = decltype(h_tag)::value, cp = decltype(cp_tag)::value;
             if (ABL == 2) return;
             const f32x4 t0 = X[2 * cp][h], t1 = X[2 * cp + 1][h];
-            Bf[h][cp] = __builtin_bit_cast(bf16x8, u32x4{pack2relu(t0[0], t0[1]), pack2relu(t0[2], t0[3]),
-                                                         pack2relu(t1[0], t1[1]), pack2relu(t1[2], t1[3])});
+            const u32x4 pk = u32x4{pack2relu(t0[0], t0[1]), pack2relu(t0[2], t0[3]), pack2relu(t1[0], t1[1]), pack2relu(t1[2], t1[3])};
+            if (ABL == 9) {      // timing probe: do the pack VALU work but leave conv2 independent of it
+                asm volatile("" ::"v"(pk));
+                return;
+            }
+            Bf[sp][h][cp] = __builtin_bit_cast(bf16x8, pk);
         };
         // conv2, one tap j of one (row, channel pair): 5 MFMAs into the accumulators of output w'-j
-        auto tap = [&](auto j_tag, auto h_tag, auto cp_tag, f32x4 (&a)[5], bool fresh) {
-            constexpr int j = decltype(j_tag)::value, h = decltype(h_tag)::value, cp = decltype(cp_tag)::value;
+        auto tap = [&](auto sp_tag, auto j_tag, auto h_tag, auto cp_tag, f32x4 (&a)[5], bool fresh) {
+            constexpr int sp = decltype(sp_tag)::value, j = decltype(j_tag)::value, h = decltype(h_tag)::value, cp = decltype(cp_tag)::value;
 #pragma unroll
             for (int ot = 0; ot < 5; ++ot) {
                 const f32x4 c = fresh ? f32x4{0.f, 0.f, 0.f, 0.f} : a[ot];
-                a[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[h][j][cp][ot], Bf[h][cp], c, 0, 0, 0);
+                a[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[h][j][cp][ot], Bf[sp][h][cp], c, 0, 0, 0);
             }
         };
         // ---- exchange of the four waves' K-quarter partials of ONE output position.  Wave q owns
@@ -234,10 +239,11 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
             }
             const f32x4 s = (rp[0] + rp[1]) + (rp[2] + rp[3]);
             u32x2 o;
-            o[0] = pack2relu(s[0] + bq.x, s[1] + bq.y);
-            o[1] = pack2relu(s[2] + bq.z, s[3] + bq.w);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bq_lds);
+            o[0] = pack2relu(s[0] + bq[0], s[1] + bq[1]);
+            o[1] = pack2relu(s[2] + bq[2], s[3] + bq[3]);
             unsigned short* dst = fbase + (long)w * kC2;
-            const float t = ((rc[0] + rc[1]) + (rc[2] + rc[3])) + b4q;
+            const float t = ((rc[0] + rc[1]) + (rc[2] + rc[3])) + *b4_lds;
             const unsigned short t16 = (unsigned short)pack2relu(t, 0.f);
             if (ABL == 7) {      // keep the values live, skip the global stores
                 asm volatile("" ::"v"(o), "v"(t16));
@@ -260,30 +266,35 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         auto step = [&](int v, auto par_next, auto first_tag, auto last_tag, f32x4 (&a0)[5], f32x4 (&a1)[5], f32x4 (&a2)[5]) {
             constexpr bool FIRST = decltype(first_tag)::value != 0, LAST = decltype(last_tag)::value != 0;
             using PB = std::integral_constant<int, 1 - decltype(par_next)::value>;      // = v & 1
-            // A: tap 2 (20 MFMAs) + pack of row 1 of this step's conv1 (issued late in the previous step)
-            if (!FIRST) { x_fence(I1{}); pack(I1{}, I0{}); pack(I1{}, I1{}); }
+            // A: tap 2 (20 MFMAs) + pack of row 1 of this step's conv1 (issued at the end of the previous step)
+            if (!FIRST) { x_fence(I1{}); pack(PB{}, I1{}, I0{}); pack(PB{}, I1{}, I1{}); }
             if (!LAST) conv1_load(v + 1, par_next, I0{});
-            tap(I2{}, I0{}, I0{}, a2, false); tap(I2{}, I0{}, I1{}, a2, false);
-            tap(I2{}, I1{}, I0{}, a2, false); tap(I2{}, I1{}, I1{}, a2, false);
+            tap(PB{}, I2{}, I0{}, I0{}, a2, false); tap(PB{}, I2{}, I0{}, I1{}, a2, false);
+            tap(PB{}, I2{}, I1{}, I0{}, a2, false); tap(PB{}, I2{}, I1{}, I1{}, a2, false);
             if (ABL == 8) MDC_SB();
-            // B: the completed output goes to LDS while tap 1 (20 MFMAs, writes a1 only) runs; conv1(v+1)
-            //    row 0; finish of output v-1
+            // B: the completed output goes to LDS while tap 1 (20 MFMAs, writes a1 only) runs; conv1(v+1) row 0
+            //    and its pack (so row 0 of X is live inside this phase only)
             part_write(PB{}, a2);
             if (!LAST) { conv1(par_next, I0{}); conv1_load(v + 1, par_next, I1{}); }
-            tap(I1{}, I0{}, I0{}, a1, false); tap(I1{}, I0{}, I1{}, a1, false);
-            if (!FIRST) red_finish(v - 1);
-            tap(I1{}, I1{}, I0{}, a1, false); tap(I1{}, I1{}, I1{}, a1, false);
+            tap(PB{}, I1{}, I0{}, I0{}, a1, false); tap(PB{}, I1{}, I0{}, I1{}, a1, false);
+            tap(PB{}, I1{}, I1{}, I0{}, a1, false);
+            if (!LAST) { x_fence(I0{}); pack(par_next, I0{}, I0{}); pack(par_next, I0{}, I1{}); }
+            tap(PB{}, I1{}, I1{}, I1{}, a1, false);
             MDC_SB();
-            // C: barrier + owner's reads of partial(v) while tap 0 (20 MFMAs, fresh a0 = the registers written
-            //    out one step ago, whose ds_writes completed at the previous barrier) runs; pack of row 0;
+            // C: finish of output v-1; barrier + owner's reads of partial(v); tap 0 (20 MFMAs, fresh a0);
             //    conv1(v+1) row 1
+            if (!FIRST) red_finish(v - 1);
             red_load(PB{});
-            tap(I0{}, I0{}, I0{}, a0, true);
-            if (!LAST) x_fence(I0{});
-            tap(I0{}, I0{}, I1{}, a0, false); if (!LAST) pack(I0{}, I0{});
-            tap(I0{}, I1{}, I0{}, a0, false); if (!LAST) pack(I0{}, I1{});
+            // HARDWARE HAZARD: a ds_write reads its data registers some time AFTER it issues (longer when the four
+            // waves' write bursts queue up), and an MFMA that overwrites them meanwhile corrupts the stored partial
+            // (VALU writes are interlocked, XDL writes are not; hipcc does not model it).  Keeping a2 alive until
+            // here -- behind the barrier's s_waitcnt lgkmcnt(0) -- stops the register allocator from handing
+            // a2's registers to any MFMA before the ds_writes have completed.
+            if (ABL != 1) asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4]));
+            tap(PB{}, I0{}, I0{}, I0{}, a0, true);  tap(PB{}, I0{}, I0{}, I1{}, a0, false);
+            tap(PB{}, I0{}, I1{}, I0{}, a0, false);
             if (!LAST) conv1(par_next, I1{});
-            tap(I0{}, I1{}, I1{}, a0, false);
+            tap(PB{}, I0{}, I1{}, I1{}, a0, false);
             MDC_SB();
         };
         using P0 = std::integral_constant<int, 0>;
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         conv1_load(0, P0{}, I0{}); conv1_load(0, P0{}, I1{});
         conv1(P0{}, I0{}); conv1(P0{}, I1{});
         x_fence(I0{}); x_fence(I1{});
-        pack(I0{}, I0{}); pack(I0{}, I1{}); pack(I1{}, I0{}); pack(I1{}, I1{});
+        pack(P0{}, I0{}, I0{}); pack(P0{}, I0{}, I1{}); pack(P0{}, I1{}, I0{}); pack(P0{}, I1{}, I1{});
         step(0, P1{}, I1{}, I0{}, acc[2], acc[1], acc[0]);
         int v = 1;
         for (int it = 0; it < 21; ++it, v += 6) {     // v = 1 .. 126
@@ -310,8 +321,12 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         step(129, P0{}, I0{}, I1{}, acc[2], acc[1], acc[0]);
         red_finish(129);
         // outputs 130 and 131 see only zero padding beyond position 131: complete as they are
-        part_write(I0{}, acc[1]); red_load(I0{}); red_finish(130);
-        part_write(I1{}, acc[2]); red_load(I1{}); red_finish(131);
+        part_write(I0{}, acc[1]); red_load(I0{});
+        asm volatile("" ::"a"(acc[1][0]), "a"(acc[1][1]), "a"(acc[1][2]), "a"(acc[1][3]), "a"(acc[1][4]));
+        red_finish(130);
+        part_write(I1{}, acc[2]); red_load(I1{});
+        asm volatile("" ::"a"(acc[2][0]), "a"(acc[2][1]), "a"(acc[2][2]), "a"(acc[2][3]), "a"(acc[2][4]));
+        red_finish(131);
 #undef MDC_SB
         __syncthreads();      // next group's image is complete; partial buffers are free again
     }
@@ -500,7 +515,7 @@ int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, 
 #ifdef MDC_ABLATIONS   // timing-only variants for tools/ablate_conv.py (build with -DMDC_ABLATIONS); results are wrong
     static const int abl = getenv("MDC_ABLATE") ? atoi(getenv("MDC_ABLATE")) : 0;
     switch (abl) { case 1: MDC_LAUNCH_CONV(1); break; case 2: MDC_LAUNCH_CONV(2); break; case 3: MDC_LAUNCH_CONV(3); break; case 5: MDC_LAUNCH_CONV(5); break;
-                  case 6: MDC_LAUNCH_CONV(6); break; case 7: MDC_LAUNCH_CONV(7); break; case 8: MDC_LAUNCH_CONV(8); break; default: MDC_LAUNCH_CONV(0); }
+                  case 6: MDC_LAUNCH_CONV(6); break; case 7: MDC_LAUNCH_CONV(7); break; case 8: MDC_LAUNCH_CONV(8); break; case 9: MDC_LAUNCH_CONV(9); break; default: MDC_LAUNCH_CONV(0); }
 #else
     MDC_LAUNCH_CONV(0);
 #endif
