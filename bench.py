@@ -36,10 +36,13 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}  # dense MFMA peaks 
 WORKLOADS = {
     # name: (topology kind, filters, classes, dtype, per-GPU frames, weights)
     "vtcnn2-c11-bf16-n2^20": ("vtcnn2", 256, 11, "bf16", 1 << 20, "synthetic seed 2016"),
+    "vtcnn2-c11-bf16-n2^21": ("vtcnn2", 256, 11, "bf16", 1 << 21, "synthetic seed 2016"),     # configs[3]: 2^24 over 8 GPUs
     "vtcnn2-c3-f32-n65536": ("vtcnn2", 256, 3, "f32", 1 << 16, "synthetic seed 2016"),
     "vtcnn2-c11-f32-n65536": ("vtcnn2", 256, 11, "f32", 1 << 16, "synthetic seed 2016"),
     "deployed3-f32-n2^20": ("deployed", 3, 3, "f32", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),
     "deployed10-f32-n2^20": ("deployed", 10, 3, "f32", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),
+    "deployed3-f32-n2^21": ("deployed", 3, 3, "f32", 1 << 21, "3convmodrecnets_CNN2_0.5 (bundled)"),        # configs[3], T1 reading
+    "cnnpy-f32-n2^20": ("cnnpy", 10, 5, "f32", 1 << 20, "synthetic seed 2016"),                           # cnn.py literal model
 }
 DEFAULT = "vtcnn2-c11-bf16-n2^20"
 EXTRAS = ["vtcnn2-c3-f32-n65536", "deployed3-f32-n2^20", "deployed10-f32-n2^20"]
@@ -50,6 +53,8 @@ def make_model(name, device):
     kind, filters, classes, dtype, n, _ = WORKLOADS[name]
     if kind == "vtcnn2":
         m = VTCNN2.synthetic(Topology.vtcnn2(classes), seed=2016, device=device, dtype=dtype)
+    elif kind == "cnnpy":
+        m = VTCNN2.synthetic(Topology.cnnpy(filters, 10, classes), seed=2016, device=device, dtype=dtype)
     else:
         g = os.path.join(ROOT, "tests", "golden", "weights")
         f = "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"
@@ -97,7 +102,8 @@ def dominant_roofline(m, x, probs, labels, steps):
         by = topo.io_bytes_per_frame * frames_per_launch
         ach = by / (avg_ms * 1e-3) / 1e9
         rl = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": ach / PEAK_HBM_GBS, "traffic": measured_traffic(f"{name}/F{topo.filters}", frames_per_launch),
+              "frac": ach / PEAK_HBM_GBS,
+              "traffic": measured_traffic(f"{name}/F{topo.filters}" if topo.kind == "deployed" else name, frames_per_launch),
               "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
     return rl, kernels
 
@@ -111,6 +117,9 @@ def cpu_baseline(name, budget_s=20.0):
     if kind == "vtcnn2":
         w = VTCNN2.synthetic(Topology.vtcnn2(classes), seed=2016).get_weights()
         sample = 512
+    elif kind == "cnnpy":
+        w = VTCNN2.synthetic(Topology.cnnpy(filters, 10, classes), seed=2016).get_weights()
+        sample = 65536
     else:
         g = os.path.join(ROOT, "tests", "golden", "weights")
         f = "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"
@@ -166,8 +175,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-        device = int(os.environ.get("LOCAL_RANK", "0"))
+        # "nccl" IS RCCL on ROCm.  MDC_BENCH_BACKEND=gloo / MDC_BENCH_ONE_DEVICE=1 exist only to rehearse the
+        # N>1 control flow on a one-GPU box (all ranks share cuda:0); the driver's scaling run uses neither.
+        dist.init_process_group(os.environ.get("MDC_BENCH_BACKEND", "nccl"))
+        device = 0 if os.environ.get("MDC_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     else:
         device = 0
     torch.cuda.set_device(device)

@@ -217,6 +217,10 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
                 return;
             }
             float* pw = part + PB * kPartFloats;
+            if (ABL == 10 && q != 0) {      // timing probe: only one wave writes (LDS burst contention)
+                for (int ot = 0; ot < 5; ++ot) asm volatile("" ::"a"(a[ot]));
+                return;
+            }
 #pragma unroll
             for (int ot = 0; ot < 5; ++ot) *reinterpret_cast<f32x4*>(pw + ((q * 5 + ot) * 64 + lane) * 4) = a[ot];
         };
@@ -515,7 +519,7 @@ int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, 
 #ifdef MDC_ABLATIONS   // timing-only variants for tools/ablate_conv.py (build with -DMDC_ABLATIONS); results are wrong
     static const int abl = getenv("MDC_ABLATE") ? atoi(getenv("MDC_ABLATE")) : 0;
     switch (abl) { case 1: MDC_LAUNCH_CONV(1); break; case 2: MDC_LAUNCH_CONV(2); break; case 3: MDC_LAUNCH_CONV(3); break; case 5: MDC_LAUNCH_CONV(5); break;
-                  case 6: MDC_LAUNCH_CONV(6); break; case 7: MDC_LAUNCH_CONV(7); break; case 8: MDC_LAUNCH_CONV(8); break; case 9: MDC_LAUNCH_CONV(9); break; default: MDC_LAUNCH_CONV(0); }
+                  case 6: MDC_LAUNCH_CONV(6); break; case 7: MDC_LAUNCH_CONV(7); break; case 8: MDC_LAUNCH_CONV(8); break; case 9: MDC_LAUNCH_CONV(9); break; case 10: MDC_LAUNCH_CONV(10); break; default: MDC_LAUNCH_CONV(0); }
 #else
     MDC_LAUNCH_CONV(0);
 #endif

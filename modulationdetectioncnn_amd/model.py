@@ -279,6 +279,25 @@ class VTCNN2:
         as_numpy, _probs, labels, _ = self._run(X, batch_size, None)
         return labels.cpu().numpy() if as_numpy else labels
 
+    # ------------------------------------------------------------------ evaluation (cnn.py:198-216)
+    def confusion(self, X, labels_true, batch_size: Optional[int] = None, normalize: bool = True) -> np.ndarray:
+        """``conf[j,k] += 1`` over (true j, predicted k) then row-normalise, as cnn.py:199-216 does with the
+        output of ``model.predict``; rows without samples stay 0."""
+        pred = self.predict_classes(X, batch_size)
+        pred = pred.cpu().numpy() if not isinstance(pred, np.ndarray) else pred
+        C = self.topology.classes
+        conf = np.zeros((C, C), np.float64)
+        np.add.at(conf, (np.asarray(labels_true, dtype=np.int64), pred.astype(np.int64)), 1.0)
+        if not normalize:
+            return conf
+        s = conf.sum(axis=1, keepdims=True)
+        return np.divide(conf, s, out=np.zeros_like(conf), where=s > 0)
+
+    def accuracy(self, X, labels_true, batch_size: Optional[int] = None) -> float:
+        """cnn.py:257-259: cor / (cor + ncor) from the un-normalised confusion counts."""
+        conf = self.confusion(X, labels_true, batch_size, normalize=False)
+        return float(np.trace(conf) / max(conf.sum(), 1.0))
+
     # ------------------------------------------------------------------ measurement hooks
     def set_profiling(self, on: bool) -> None:
         _cabi.check(_cabi.lib().mdc_set_profiling(self._engine(), int(on)))

@@ -161,3 +161,14 @@ def test_txt_weights_load_and_classify(tmp_path):
     p.write_text(q612.dump_weights_f3(w))
     m2 = VTCNN2.from_txt(str(p))
     assert m2.predict_classes(x).tolist() == fz["labels"]
+
+
+def test_confusion_and_accuracy_match_reference_loop():
+    """cnn.py:199-216,257-259 on top of predict(): confusion matrix and accuracy."""
+    m = _model("3convmodrecnets_CNN2_0.5")
+    x = synthetic_frames(999, seed=21)
+    y = np.arange(999) % 3
+    w = [a for p in load_deployed_npz("3convmodrecnets_CNN2_0.5") for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)
+    np.testing.assert_allclose(m.confusion(x, y), O.confusion(y, ref["labels"], 3), atol=1e-12)
+    assert abs(m.accuracy(x, y) - float((ref["labels"] == y).mean())) < 1e-12
