@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void deployed_tap_kernel(const float* __restri
 // 12+12 adds for the two bank levels, 6 inside the bank, 2 permlane swaps per class across the four
 // 16-lane rows) instead of a full 6-step wave reduction per value; (b) the 129th conv position
 // (w = 0), which only one lane per row owns, is not a fifth slot any more: the position is evaluated once per 64-frame
-// block for all frames at once, with scalar weights (x[h][0] is re-read by the finishing lane: an L2 hit).
+// block for all frames at once, with scalar weights (x[h][0] travels through a 512-byte LDS table).
 // Result lane of frame j = 4G + f of the block:  16*(G>>2) + 4*bank(f) + (G&3),  bank = {0,2,1,3}[f].
 // ---------------------------------------------------------------------------------------------
 template <int CTRL, int BANK_MASK>
@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
     }
     // dense weights of position w = 0 of row 0 / row 1 (wave-uniform): slot 4 of lanes 0 and 32
     const float* we0 = wp + kHeadFloats + (4 * F * kC) * 64;
+    __shared__ float e_lds[4][128];
+    float* e_tab = e_lds[(threadIdx.x >> 6) & 3];
     // lane -> block-relative frame it finishes
     const int myG = 4 * (lane >> 4) + (lane & 3);
     const int myb = (lane >> 2) & 3;
@@ -207,14 +209,9 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
     for (long blk = (long)blockIdx.x * 4 + wv; blk < nblk; blk += nwaves) {
         const long base = blk << 6;
         float r[kC] = {0.f, 0.f, 0.f};
-        // x[0][0] / x[1][0] of the frame this lane finishes: two 4-byte gathers per 64-frame block, issued now and
-        // consumed after the last group (the lines are the ones the streaming loads below fetch anyway)
+        // x[0][0] / x[1][0] of every frame go through a 512-byte LDS table (written by lanes 0 and 32 as the
+        // frames stream by, read once per block by the lane that finishes the frame): no extra HBM/L2 reads
         float eI = 0.f, eQ = 0.f;
-        if (!(ABL & 1) && (!TAIL || myframe < n)) {
-            const float* pe = x + (base + myframe) * kFrameFloats;
-            eI = pe[0];
-            eQ = pe[kSamples];
-        }
         const float4* px = reinterpret_cast<const float4*>(x + base * kFrameFloats) + lane;
         float4 cur[4], nx[4];
         auto load = [&](int j) {
@@ -237,6 +234,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                 float nxt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cur[f].x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
                 nxt = (lp == 31) ? 0.f : nxt;
                 const float xs[5] = {cur[f].x, cur[f].y, cur[f].z, cur[f].w, nxt};
+                if (!(ABL & 1) && lp == 0) e_tab[(4 * G + f) * 2 + (lane >> 5)] = cur[f].x;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f;
                 if (ABL & 4) { s0 = xs[0] + xs[1]; s1 = xs[2] + xs[3]; s2 = xs[4]; }     // memory-only probe
                 else
@@ -291,6 +289,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
             for (int f = 0; f < 4; ++f) cur[f] = nx[f];
         }
         // ---- position w = 0 of both rows, all 64 frames at once: y = relu(b + K1*x[h][0]) (x[h][-1] = 0)
+        if (!(ABL & 1)) { eI = e_tab[myframe * 2 + 0]; eQ = e_tab[myframe * 2 + 1]; }
 #pragma unroll
         for (int ff = 0; ff < F; ++ff) {
             const float yI = fmaxf(fmaf(k1[ff], eI, cb[ff]), 0.f);
