@@ -1,7 +1,8 @@
 // Canonical VT-CNN2 (T3), bf16 MFMA path (f32 accumulation).  See vtcnn2.hip for the math and
 // the "lane = frame" mapping.
 //
-// vt_conv_bf16_kernel -- WEIGHT-STATIONARY IN REGISTERS.  The conv2 kernel tensor is
+// vt_conv_bf16_kernel / vt_conv_bf16_sched_kernel -- WEIGHT-STATIONARY IN REGISTERS.  (The second is the
+// production kernel: same algorithm, instruction order written by hand; the first is scheduled by hipcc.)  The conv2 kernel tensor is
 // 80 x 1536 bf16 = 240 KiB: too big for the 160 KiB LDS, but a CU's four SIMDs hold 512 KiB
 // of registers.  One workgroup = 4 waves (one per SIMD, 512 VGPR+AGPR each); wave q keeps the
 // conv2 weights of input channels [64q, 64q+64) for all 80 outputs, 2 rows and 3 taps:
@@ -524,39 +525,40 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
         *reinterpret_cast<u32x2*>(dst + 16 * q) = u32x2{fo.o0, fo.o1};
         dst[64 + q] = fo.t16;
     }
-    sch_tap<1, 1, 0, 0>(st, a1);
-    sch_tap<1, 1, 0, 1>(st, a1); sch_part_write<PAR, 0>(st, a2[0]);
-    sch_tap<1, 1, 0, 2>(st, a1);
+    sch_tap<1, 1, 0, 0>(st, a1); sch_part_write<PAR, 0>(st, a2[0]);
+    sch_tap<1, 1, 0, 1>(st, a1);
+    sch_tap<1, 1, 0, 2>(st, a1); sch_part_write<PAR, 1>(st, a2[1]);
     sch_tap<1, 1, 0, 3>(st, a1);
-    sch_tap<1, 1, 0, 4>(st, a1); sch_part_write<PAR, 1>(st, a2[1]);
+    sch_tap<1, 1, 0, 4>(st, a1); sch_part_write<PAR, 2>(st, a2[2]);
     sch_tap<1, 1, 1, 0>(st, a1);
-    sch_tap<1, 1, 1, 1>(st, a1);
-    sch_tap<1, 1, 1, 2>(st, a1); sch_part_write<PAR, 2>(st, a2[2]);
-    sch_tap<1, 1, 1, 3>(st, a1);
+    sch_tap<1, 1, 1, 1>(st, a1); sch_part_write<PAR, 3>(st, a2[3]);
+    sch_tap<1, 1, 1, 2>(st, a1);
+    sch_tap<1, 1, 1, 3>(st, a1); sch_part_write<PAR, 4>(st, a2[4]);
     sch_tap<1, 1, 1, 4>(st, a1);
-    sch_tap<1, 0, 0, 0>(st, a1); sch_part_write<PAR, 3>(st, a2[3]);
+    sch_tap<1, 0, 0, 0>(st, a1);
     sch_tap<1, 0, 0, 1>(st, a1);
     sch_tap<1, 0, 0, 2>(st, a1);
-    sch_tap<1, 0, 0, 3>(st, a1); sch_part_write<PAR, 4>(st, a2[4]);
+    sch_tap<1, 0, 0, 3>(st, a1);
     sch_tap<1, 0, 0, 4>(st, a1);
     sch_tap<1, 0, 1, 0>(st, a1);
     sch_tap<1, 0, 1, 1>(st, a1);
     sch_tap<1, 0, 1, 2>(st, a1);
     sch_tap<1, 0, 1, 3>(st, a1);
     sch_tap<1, 0, 1, 4>(st, a1);
-    // ---------------- C: exchange hand-off; tap 0 (fresh accumulators) with the reads of partial(v) in its
-    //                  first shadows; pack of conv1 row 1
+    // ---------------- C: tap 0 (fresh accumulators); the exchange hand-off (barrier) a few MFMAs in, so that the
+    //                  ds_writes above have long completed when lgkmcnt(0) is asked for; then the reads of
+    //                  partial(v) in the following shadows; pack of conv1 row 1
+    sch_tap<0, 1, 0, 0, true>(st, a0);
+    sch_tap<0, 1, 0, 1, true>(st, a0);
+    sch_tap<0, 1, 0, 2, true>(st, a0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    sch_tap<0, 1, 0, 0, true>(st, a0); sch_red_load1<PAR, 0>(st);
-    sch_tap<0, 1, 0, 1, true>(st, a0); sch_red_load1<PAR, 1>(st);
-    sch_tap<0, 1, 0, 2, true>(st, a0); sch_red_load1<PAR, 2>(st);
-    sch_tap<0, 1, 0, 3, true>(st, a0); sch_red_load1<PAR, 3>(st);
-    sch_tap<0, 1, 0, 4, true>(st, a0);
-    // keep a2 allocated until here (see the ds_write / XDL hazard note above): its ds_writes completed at the
-    // lgkmcnt(0) in front of the barrier, and no MFMA issued since then can have been given its registers
+    // keep a2 allocated until here (see the ds_write / XDL hazard note above): its ds_writes have completed, and
+    // no MFMA issued before this point can have been given its registers
     asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4]));
-    sch_tap<0, 1, 1, 0>(st, a0);
-    sch_tap<0, 1, 1, 1>(st, a0);
+    sch_tap<0, 1, 0, 3, true>(st, a0); sch_red_load1<PAR, 0>(st);
+    sch_tap<0, 1, 0, 4, true>(st, a0); sch_red_load1<PAR, 1>(st);
+    sch_tap<0, 1, 1, 0>(st, a0); sch_red_load1<PAR, 2>(st);
+    sch_tap<0, 1, 1, 1>(st, a0); sch_red_load1<PAR, 3>(st);
     sch_tap<0, 1, 1, 2>(st, a0);
     sch_tap<0, 1, 1, 3>(st, a0);
     sch_tap<0, 1, 1, 4>(st, a0);
@@ -868,7 +870,9 @@ int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, 
     switch (abl) { case 1: MDC_LAUNCH_CONV(1); break; case 2: MDC_LAUNCH_CONV(2); break; case 3: MDC_LAUNCH_CONV(3); break; case 5: MDC_LAUNCH_CONV(5); break;
                   case 6: MDC_LAUNCH_CONV(6); break; case 7: MDC_LAUNCH_CONV(7); break; case 8: MDC_LAUNCH_CONV(8); break; case 9: MDC_LAUNCH_CONV(9); break; case 10: MDC_LAUNCH_CONV(10); break; default: MDC_LAUNCH_CONV(0); }
 #else
-    static const bool sched = getenv("MDC_CONV_SCHED") != nullptr;
+    // default: the asm-sequenced step; MDC_CONV_SCHED=0 selects the hipcc-scheduled kernel (same results up to
+    // summation order inside an accumulator chain) for A/B timing
+    static const bool sched = !(getenv("MDC_CONV_SCHED") && atoi(getenv("MDC_CONV_SCHED")) == 0);
     if (sched) {
         MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_sched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds));
         hipLaunchKernelGGL(vt_conv_bf16_sched_kernel, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n,
