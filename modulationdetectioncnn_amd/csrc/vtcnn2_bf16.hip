@@ -21,7 +21,10 @@
 //
 // vt_dense1_bf16_kernel -- 256x256x64-tile bf16 GEMM (M = frames, N = 256 hidden units,
 // K = 10560), LDS-DMA staging with an XOR-swizzled source (so ds_read_b128 fragments spread
-// over the banks), two LDS buffers, 8 waves (2 x 4), fused bias + ReLU epilogue.
+// over the banks), two LDS buffers, 8 waves (2 x 4), fused bias + ReLU epilogue.  48 % MFMA-busy;
+// SQ_WAIT_ANY is 44 % of its wave cycles.  (Tried and dropped: a ring of four 32-deep stages with a
+// counted vmcnt(8) -- 6 % slower: the waits are the per-k-step LDS fragment reads and the barrier, not HBM
+// latency; the next step for this kernel is fragment prefetch into registers / the 8-phase schedule.)
 #include "mdc_internal.h"
 
 #include <cstdlib>
