@@ -152,12 +152,15 @@ __global__ __launch_bounds__(256) void dense_chain_kernel(ChainParams p) {
             const float mx = row_allreduce(zz, [](float a, float b) { return fmaxf(a, b); });
             const float e = cls ? expf(zz - mx) : 0.f;
             const float sum = row_allreduce(e, [](float a, float b) { return a + b; });
-            // np.argmax: FIRST index attaining the maximum (cnn.py:209)
-            const float cand = (zz == mx) ? (float)fr : 1e9f;
+            const float pv = e / sum;
+            // int(np.argmax(test_Y_hat[i,:])) (cnn.py:209): FIRST index attaining the maximum of the
+            // PROBABILITIES as returned (slightly different logits can round to the same probability)
+            const float pmx = row_allreduce(cls ? pv : -1.f, [](float a, float b) { return fmaxf(a, b); });
+            const float cand = (cls && pv == pmx) ? (float)fr : 1e9f;
             const float arg = row_allreduce(cand, [](float a, float b) { return fminf(a, b); });
             if (row < p.n) {
                 if (cls) {
-                    if (p.probs) p.probs[row * p.n_out + fr] = e / sum;
+                    if (p.probs) p.probs[row * p.n_out + fr] = pv;
                     if (p.tap_logits) p.tap_logits[row * p.n_out + fr] = z[r];
                 }
                 if (fr == 0 && p.labels) p.labels[row] = (int)arg;

@@ -123,15 +123,15 @@ __global__ __launch_bounds__(256) void deployed_tap_kernel(const float* __restri
             const float e0 = expf(z0 - mx), e1 = expf(z1 - mx), e2 = expf(z2 - mx);
             const float inv = 1.0f / (e0 + e1 + e2);
             const long o = base + lane;
+            const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
             if (probs) {
-                probs[o * 3 + 0] = e0 * inv;
-                probs[o * 3 + 1] = e1 * inv;
-                probs[o * 3 + 2] = e2 * inv;
+                probs[o * 3 + 0] = p0;
+                probs[o * 3 + 1] = p1;
+                probs[o * 3 + 2] = p2;
             }
-            // np.argmax: first maximum.  exp and the common scale are monotone, so the
-            // argmax of the probabilities is the argmax of z (ties included: equal z give
-            // bit-equal e).
-            if (labels) labels[o] = (z0 >= z1 && z0 >= z2) ? 0 : ((z1 >= z2) ? 1 : 2);
+            // int(np.argmax(test_Y_hat[i,:])) (cnn.py:209): FIRST maximum of the PROBABILITIES as returned --
+            // two slightly different z can round to the same probability, and then the lower index wins
+            if (labels) labels[o] = (p0 >= p1 && p0 >= p2) ? 0 : ((p1 >= p2) ? 1 : 2);
             if (TAP == 2) {
                 tap_dense[o * 3 + 0] = z0;
                 tap_dense[o * 3 + 1] = z1;
@@ -308,13 +308,14 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
             const float mx = fmaxf(z0, fmaxf(z1, z2));
             const float e0 = expf(z0 - mx), e1 = expf(z1 - mx), e2 = expf(z2 - mx);
             const float inv = 1.0f / (e0 + e1 + e2);
+            const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
             if (probs) {
-                probs[o * 3 + 0] = e0 * inv;
-                probs[o * 3 + 1] = e1 * inv;
-                probs[o * 3 + 2] = e2 * inv;
+                probs[o * 3 + 0] = p0;
+                probs[o * 3 + 1] = p1;
+                probs[o * 3 + 2] = p2;
             }
-            // np.argmax: first maximum (equal z give bit-equal e, so argmax z == argmax p, ties included)
-            if (labels) labels[o] = (z0 >= z1 && z0 >= z2) ? 0 : ((z1 >= z2) ? 1 : 2);
+            // int(np.argmax(test_Y_hat[i,:])) (cnn.py:209): FIRST maximum of the probabilities as returned
+            if (labels) labels[o] = (p0 >= p1 && p0 >= p2) ? 0 : ((p1 >= p2) ? 1 : 2);
             if (TAP == 2) {
                 tap_dense[o * 3 + 0] = z0;
                 tap_dense[o * 3 + 1] = z1;

@@ -44,10 +44,13 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 namespace {
 
-constexpr int kPairs = 66;                        // 132 padded samples per row, as bf16 pairs
+// 132 padded samples per row = 66 bf16 pairs, plus one more zero pair: conv1 at an odd position v reads pairs
+// i, i+1, i+2 (i = v>>1) and v = 129 touches pair 66.  Its sample only meets a zero tap, but 0 x (Inf/NaN bit
+// pattern from whatever follows the image in LDS) is NaN, so the pair has to exist and hold a finite value.
+constexpr int kPairs = 67;
 constexpr int kImgWords = 2 * kPairs * 64;        // [row h][pair][lane]  u32
 constexpr int kPartFloats = 4 * 5 * 64 * 4;       // [wave][ot][lane][4]  f32
-constexpr size_t kConvBf16Lds = (size_t)2 * kImgWords * 4 + (size_t)2 * kPartFloats * 4 + 512;   // 109,056 B (+ conv2 bias)
+constexpr size_t kConvBf16Lds = (size_t)2 * kImgWords * 4 + (size_t)2 * kPartFloats * 4 + 512;   // 110,080 B (+ conv2 bias)
 constexpr int kWFrags = 2 * 3 * 2 * 5;            // [h][j][cp][ot] = 60 fragments per wave
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {          // two f32 -> packed bf16 (RNE)
