@@ -1,0 +1,24 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun) from the repo root: collects the rocprofv3 data behind profiles/.
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh'
+# then, back in the container:  python tools/summarize_profiles.py r01
+# Kernel timing and PMC counters are separate runs (gpurun refuses --pmc combined with API traces), and
+# FETCH_SIZE / WRITE_SIZE are separate passes as MI355X_MICROARCH.md prescribes.
+set -e -o pipefail
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+P="--output-format csv"
+if [ "$1" != "dep" ]; then
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_r01_bench -- python3 $R/bench.py --steps 10 --warmup 3 > $R/gpurun_out/prof_r01_bench.log 2>&1
+echo "kernel stats done"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt -- $B > $R/gpurun_out/pmc_fetch_vt.log 2>&1
+rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_vt -- $B > $R/gpurun_out/pmc_write_vt.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA $P -d $R/gpurun_out/pmc_mfma_vt -- $B > $R/gpurun_out/pmc_mfma_vt.log 2>&1
+echo "vtcnn2 counters done"
+fi
+D="python3 $R/tools/prof_deployed.py"
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_r01_dep -- $D > $R/gpurun_out/prof_r01_dep.log 2>&1
+rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_dep -- $D > $R/gpurun_out/pmc_fetch_dep.log 2>&1
+rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_dep -- $D > $R/gpurun_out/pmc_write_dep.log 2>&1
+echo "deployed done"

@@ -40,7 +40,7 @@ for d in sorted(glob.glob(os.path.join(G, "prof_*"))):
         shutil.copy(f, os.path.join(P, (tag if tag.startswith(rnd) else f"{rnd}_{tag}") + "_kernel_stats.csv"))
 
 spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in that run)
-    ("mdc_vt_conv/bf16", "vt", "vt_conv_bf16_kernel<0>", 65536),
+    ("mdc_vt_conv/bf16", "vt", "vt_conv_bf16", 65536),
     ("mdc_vt_dense1/bf16", "vt", "vt_dense1_bf16", 65536),
     ("mdc_vt_head", "vt", "vt_head_kernel", 65536),
     ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3", 1 << 20),
@@ -58,3 +58,18 @@ for key, sfx, kern, frames in spec:
                            "hbm_bytes_per_frame": (rd_b + wr_b) / frames}
 json.dump(out, open(os.path.join(P, f"{rnd}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# MFMA-pipe utilisation of the bf16 VT-CNN2 kernels (own --pmc pass): busy = SQ_VALU_MFMA_BUSY_CYCLES /
+# (4 SIMDs x 256 CUs x cycles), cycles = GRBM_GUI_ACTIVE summed over the 8 XCDs / 8.
+mf = {}
+for key, kern in (("mdc_vt_conv/bf16", "vt_conv_bf16"), ("mdc_vt_dense1/bf16", "vt_dense1_bf16")):
+    c = counters("pmc_mfma_vt", kern)
+    if not c:
+        continue
+    cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+    mf[key] = {"GRBM_GUI_ACTIVE_sum": c["GRBM_GUI_ACTIVE"], "cycles_per_launch": cyc, "SQ_INSTS_MFMA": c["SQ_INSTS_MFMA"],
+               "SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"],
+               "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cyc)}
+if mf:
+    json.dump(mf, open(os.path.join(P, f"{rnd}_mfma.json"), "w"), indent=1)
+    print(json.dumps(mf, indent=1))
