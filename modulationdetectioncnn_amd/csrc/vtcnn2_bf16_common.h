@@ -1,0 +1,76 @@
+// Shared by the bf16 VT-CNN2 kernel files (vtcnn2_bf16.hip, vtcnn2_bf16_sched.hip, vtcnn2_bf16_dense1.hip):
+// vector typedefs, the LDS image geometry of the conv kernels, bf16 packing helpers and the frame staging.
+#pragma once
+#include "mdc_internal.h"
+
+namespace mdc {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x2 = __attribute__((ext_vector_type(2))) short;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+namespace {
+
+// 132 padded samples per row = 66 bf16 pairs, plus one more zero pair: conv1 at an odd position v reads pairs
+// i, i+1, i+2 (i = v>>1) and v = 129 touches pair 66.  Its sample only meets a zero tap, but 0 x (Inf/NaN bit
+// pattern from whatever follows the image in LDS) is NaN, so the pair has to exist and hold a finite value.
+constexpr int kPairs = 67;
+constexpr int kImgWords = 2 * kPairs * 64;        // [row h][pair][lane]  u32
+constexpr int kPartFloats = 4 * 5 * 64 * 4;       // [wave][ot][lane][4]  f32
+constexpr size_t kConvBf16Lds = (size_t)2 * kImgWords * 4 + (size_t)2 * kPartFloats * 4 + 512;   // 110,080 B (+ conv2 bias)
+constexpr int kWFrags = 2 * 3 * 2 * 5;            // [h][j][cp][ot] = 60 fragments per wave
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {          // two f32 -> packed bf16 (RNE)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ unsigned pack2relu(float a, float b) {      // + ReLU on the packed halves
+    s16x2 s = __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    s = __builtin_elementwise_max(s, s16x2{0, 0});                     // negative bf16 <=> negative int16
+    return __builtin_bit_cast(unsigned, s);
+}
+__device__ __forceinline__ float bf16_hi_as_f32(float a) {             // value of bf16(a), as f32
+    return __uint_as_float(pack2(a, 0.f) << 16);
+}
+
+// Staging of a 16-frame group: 1024 float4 = 4 per thread, done one float4 ("quarter" k) at a time so
+// that the few registers it needs are live only briefly (the main loop sits at the register limit).
+// Image word for lane (frame i, k-group kg): kg 0 = bf16 hi pair, kg 1 = lo pair (x - hi), kg 2 = hi pair
+// again (multiplied by the low halves of the taps), kg 3 = constant (1,1) (bias slots; written once).
+__device__ __forceinline__ void stage_quarter(int k, const float* __restrict__ x, long n, long frame0,
+                                              unsigned* __restrict__ im, int tid) {
+    const int idx = tid + 256 * k;
+    const int i = idx >> 6, l = idx & 63;
+    const long f = frame0 + i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < n) v = reinterpret_cast<const float4*>(x + f * kFrameFloats)[l];
+    const int h = l >> 5, m = l & 31;
+    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float a = xs[2 * e], b = xs[2 * e + 1];
+        const unsigned hi = pack2(a, b);
+        const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
+        const unsigned lo = pack2(a - ah, b - bh);
+        unsigned* d = im + (h * kPairs + 2 * m + 1 + e) * 64 + i;   // samples 4m+2e, +1 -> padded 4m+2e+2, +3
+        d[0] = hi;
+        d[16] = lo;
+        d[32] = hi;
+    }
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+}  // namespace
+
+// launcher of the asm-sequenced conv kernel (vtcnn2_bf16_sched.hip); same arguments as vtcnn2_bf16_conv
+int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
+
+}  // namespace mdc
