@@ -41,13 +41,18 @@ __device__ __forceinline__ float bf16_hi_as_f32(float a) {             // value 
 // that the few registers it needs are live only briefly (the main loop sits at the register limit).
 // Image word for lane (frame i, k-group kg): kg 0 = bf16 hi pair, kg 1 = lo pair (x - hi), kg 2 = hi pair
 // again (multiplied by the low halves of the taps), kg 3 = constant (1,1) (bias slots; written once).
-__device__ __forceinline__ void stage_quarter(int k, const float* __restrict__ x, long n, long frame0,
-                                              unsigned* __restrict__ im, int tid) {
+// The two halves of it are separate so that the asm-sequenced kernel can issue the global load several steps
+// before it converts and stores the values (a load waited for right away sits behind every feature store in flight).
+__device__ __forceinline__ float4 stage_load(int k, const float* __restrict__ x, long n, long frame0, int tid) {
+    const int idx = tid + 256 * k;
+    const long f = frame0 + (idx >> 6);
+    // unconditional (clamped) load: a load under an exec mask gets its s_waitcnt vmcnt(0) right at the join
+    return reinterpret_cast<const float4*>(x + (f < n ? f : n - 1) * kFrameFloats)[idx & 63];
+}
+__device__ __forceinline__ void stage_write(int k, float4 v, long n, long frame0, unsigned* __restrict__ im, int tid) {
     const int idx = tid + 256 * k;
     const int i = idx >> 6, l = idx & 63;
-    const long f = frame0 + i;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < n) v = reinterpret_cast<const float4*>(x + f * kFrameFloats)[l];
+    if (frame0 + i >= n) v = make_float4(0.f, 0.f, 0.f, 0.f);      // frames past the end of the batch are zeros
     const int h = l >> 5, m = l & 31;
     const float xs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -61,6 +66,10 @@ __device__ __forceinline__ void stage_quarter(int k, const float* __restrict__ x
         d[16] = lo;
         d[32] = hi;
     }
+}
+__device__ __forceinline__ void stage_quarter(int k, const float* __restrict__ x, long n, long frame0,
+                                              unsigned* __restrict__ im, int tid) {
+    stage_write(k, stage_load(k, x, n, frame0, tid), n, frame0, im, tid);
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

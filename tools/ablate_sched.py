@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Timing-only probes of the asm-sequenced bf16 conv kernel (MDC_ABLATE_S: 1 no s_barrier, 2 no exchange,
-3 no finish/stores, 4 no pack, 5 no conv1, 6 MFMAs only).  Results are wrong by construction; only the kernel time is read."""
+3 no finish/stores, 5 no conv1+pack, 6 conv2 MFMAs only).  Results are wrong by construction; only the kernel time is read."""
 import os, subprocess, sys, json
 sys.path.insert(0, ".")
 from modulationdetectioncnn_amd import build as _b
 _b.build(force=True, extra_flags=["-DMDC_ABLATIONS"])   # NOTE: rebuild without the flag afterwards
-for abl in (sys.argv[1:] or ["0", "1", "2", "3", "4", "5", "6"]):
+for abl in (sys.argv[1:] or ["0", "1", "2", "3", "5", "6"]):
     env = dict(os.environ, MDC_ABLATE_S=abl)
     r = subprocess.run([sys.executable, "bench.py", "--no-extras", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"],
                        env=env, capture_output=True, text=True)
@@ -14,3 +14,4 @@ for abl in (sys.argv[1:] or ["0", "1", "2", "3", "4", "5", "6"]):
         print("ABLATE", abl, {k: round(v["ms_per_step"], 2) for k, v in j["kernels"].items()}, "value %.3g" % j["value"], flush=True)
     except Exception as e:
         print("ABLATE", abl, "failed", e, r.stderr[-500:])
+        sys.exit(1)      # never start another GPU run after a failed one
