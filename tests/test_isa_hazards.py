@@ -1,0 +1,33 @@
+"""The asm-sequenced conv kernel relies on an instruction ORDER for hazards the compiler does not model.  One of
+them depends on register allocation (store operands reused as the destination of a following VGPR-writing MFMA,
+tools/lint_async_hazards.py): check the generated ISA on every build.  CPU only (hipcc cross-compiles)."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_sched_kernel_has_no_store_vs_mfma_hazard():
+    spec = importlib.util.spec_from_file_location("lint_async_hazards", os.path.join(ROOT, "tools", "lint_async_hazards.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_sched.hip"), "vt_conv_bf16_sched_kernelILi0")
+    assert sum(1 for x in isa if x.startswith("v_mfma")) > 1000          # the kernel was found and is unrolled
+    assert sum(1 for x in isa if x.startswith("global_store")) >= 40
+    assert lint.lint(isa) == []
+
+
+def test_lint_flags_the_pattern():
+    spec = importlib.util.spec_from_file_location("lint_async_hazards", os.path.join(ROOT, "tools", "lint_async_hazards.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    bad = ["global_store_dwordx2 v[136:137], v[134:135], off", "v_mfma_f32_16x16x16_bf16 v[134:137], v[164:165], v[176:177], 0"]
+    assert len(lint.lint(bad)) == 1
+    ok = ["global_store_dwordx2 v[136:137], v[134:135], off", "v_mfma_f32_16x16x32_bf16 a[0:3], v[164:167], v[176:179], a[0:3]"]
+    assert lint.lint(ok) == []
+    waited = ["ds_write_b128 v10, v[20:23]", "s_waitcnt lgkmcnt(0)", "v_mfma_f32_16x16x16_bf16 v[20:23], v[1:2], v[3:4], 0"]
+    assert lint.lint(waited) == []
