@@ -71,7 +71,7 @@ def lint(isa):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_sched.hip")
+    src = os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_sched.hip")
     kernel = sys.argv[2] if len(sys.argv) > 2 else "vt_conv_bf16_sched_kernelILi0"
     isa = kernel_isa(src, kernel)
     found = lint(isa)
