@@ -284,19 +284,6 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
     }
 }
 
-inline unsigned short f2bf(float f) {          // host RNE f32 -> bf16
-    unsigned u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-inline float bf2f(unsigned short h) {
-    unsigned u = (unsigned)h << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
 
 }  // namespace
 
@@ -350,7 +337,8 @@ int vtcnn2_bf16_pack(mdc_model* m) {
             const float* src = w1 + (size_t)(o * kW2 + w) * kHid;
             for (int nn = 0; nn < kHid; ++nn) w1t[(size_t)nn * kFeat + (w * kC2 + o)] = f2bf(src[nn]);
         }
-    return upload(m, 3, w1t.data(), w1t.size() * 2);
+    if ((rc = upload(m, 3, w1t.data(), w1t.size() * 2))) return rc;
+    return vtcnn2_bf16_pack_sched(m);      // operands of the asm-sequenced conv kernel (its own K order)
 }
 
 int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {

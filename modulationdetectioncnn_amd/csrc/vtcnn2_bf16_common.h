@@ -3,6 +3,8 @@
 #pragma once
 #include "mdc_internal.h"
 
+#include <cstring>
+
 namespace mdc {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -77,9 +79,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// host-side bf16 conversion for the operand packing
+inline unsigned short f2bf(float f) {          // host RNE f32 -> bf16
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+inline float bf2f(unsigned short h) {
+    unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
 }  // namespace
 
 // launcher of the asm-sequenced conv kernel (vtcnn2_bf16_sched.hip); same arguments as vtcnn2_bf16_conv
 int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
+// its operand packing (d_pack slots 6 and 7); called by vtcnn2_bf16_pack
+int vtcnn2_bf16_pack_sched(mdc_model* m);
 
 }  // namespace mdc

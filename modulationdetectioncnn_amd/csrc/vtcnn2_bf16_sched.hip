@@ -1,5 +1,5 @@
-// Canonical VT-CNN2 (T3), bf16 path: the production conv1+conv2 kernel (see vtcnn2_bf16.hip for the algorithm,
-// the MFMA operand layouts and the hipcc-scheduled statement of the same computation).
+// Canonical VT-CNN2 (T3), bf16 path: the production conv1+conv2 kernel (see vtcnn2_bf16.hip for the algorithm
+// and the hipcc-scheduled statement of the same computation; operand layouts of THIS kernel are described here).
 #include "vtcnn2_bf16_common.h"
 
 #include <cstdlib>
@@ -13,66 +13,78 @@ namespace {
 // vt_conv_bf16_sched_kernel: every instruction of the position step is an `asm volatile` statement, so the
 // ORDER is the one written here (hipcc only allocates registers).  One wave per SIMD issues in order; what a
 // filler instruction placed between two back-to-back MFMAs costs was measured with tools/microbench/mfma_gap.hip
-// (cycles added to the 16.4-cycle MFMA gap, one wave per SIMD, AGPR accumulators):
+// (cycles added to the 16.4-cycle gap of v_mfma_f32_16x16x32_bf16, one wave per SIMD, AGPR accumulators):
 //     1 VALU (v_add_f32, v_cvt_pk_bf16_f32, DPP mov)  +0.4      v_alignbit / v_pk_max_i16 / v_lshl_add_u64  +1.2
 //     2 VALU  +4.4        3 VALU  +12        v_pk_add_f32  +16.6 (packed f32 is NOT cheap beside an MFMA)
 //     1 ds_read_b32/b64/b128  +3             VALU + ds_read in ONE gap  +12        two ds_reads in one gap  +11.5
 //     ds_write_b128  +16 (b64: +8)           global_store_dwordx2 +4, _short +16, both in one gap +44
-//     the K=16 MFMA (v_mfma_f32_16x16x16_bf16) takes the same 16.3 cycles as the K=32 one
-// Hence the rule of this schedule: ONE non-MFMA instruction per gap, all 68 gaps of a step used, the few items
-// beyond 68 doubled up as VALU+VALU.  (The first version bunched 2-4 VALU and LDS instructions in some gaps and
-// used v_pk_add_f32: its non-MFMA work cost its full issue time, 600 cycles on a 1100-cycle MFMA floor.)
+//     v_mfma_f32_16x16x16_bf16 takes the same 16.3 cycles as the K=32 shape; v_mfma_f32_32x32x16_bf16 takes 32.0 and
+//     its gap holds two VALU for free, VALU + ds_read for +3
+// Hence the rule of this schedule: ONE non-MFMA instruction per 16-cycle gap, every gap of a step used, the few
+// items beyond that doubled up as VALU+VALU.  (The first version bunched 2-4 VALU and LDS instructions in some
+// gaps and used v_pk_add_f32: its non-MFMA work cost its full issue time, 600 cycles on a 1100-cycle MFMA floor.)
 //
-// Step v (accumulators: a0 = output v+2, fresh; a1 = v+1; a2 = v, completes), 68 MFMAs:
-//   T2  tap 2 (20)      gaps: finish of output v-1 (21 VALU: sum of the 4 partials, ReLU, bf16), conv1 operand words
-//   C1  conv1(v+1) (8)  gaps: the 5 ds_write_b128 of a2 = partial(v), the 2 feature stores of output v-1
-//   T1  tap 1 (20)      gaps: 20 of the 32 pack VALU of conv1(v+1) (v_cvt_pk_bf16_f32, v_pk_max_i16 = ReLU)
+// Step v (accumulators: a0 = output v+2, fresh; a1 = v+1; a2 = v, completes), 62 MFMAs:
+//   T2  tap 2 (20)      gaps: finish of output v-1 (21 VALU: sum of the 4 partials, ReLU, bf16), conv1 operand dwords
+//   C1  conv1(v+1): 2 x v_mfma_f32_32x32x16_bf16 (M = 32 channels, N = 16 frames x 2 I/Q rows, K = 16 slots)
+//   T1  tap 1 (20)      gaps: the 2 feature stores of output v-1, ds_writes of a2 = partial(v), pack VALU of conv1(v+1)
 //   T0  tap 0 (20, 5 fresh with C = conv2 bias on wave 0)
-//                       gaps: lgkmcnt(0)+s_barrier after the 3rd MFMA, 8 ds_reads of partial(v), 12 pack VALU,
-//                       every 4th step the two ds_read_b64 of the next operand chunk
-// Bf (packed ReLU'd conv1 output = B operand of conv2) is double-buffered by step parity.
-// Image layout of THIS kernel: [buffer][row][lane][70 words], words = bf16 pairs of the padded row (lane = frame +
-// 16*k-group as in vtcnn2_bf16.hip).  A lane's pairs are contiguous, so the conv1 operands of four positions are
-// one ds_read_b64 per row (pairs 2c+2, 2c+3 of chunk c = v>>2; the other half is the previous chunk's), held in
-// three rotating register pairs; stride 70 = 2 mod 4 keeps ds_read_b64 conflict-free.
+//                       gaps: lgkmcnt(0)+s_barrier after the 3rd MFMA, 8 ds_reads of partial(v), pack VALU,
+//                       every 2nd step one LDS read of conv1 operands
+// conv1 on the 32x32 shape: the MFMA's column is (frame, row), so its result holds BOTH rows of a frame in lanes
+// f+16h (+32 for the upper k-half): packed to bf16 it is a B operand of conv2's 16x16x32 MFMA whose K index mixes
+// rows and channels -- conv2 sums over both, so only the weight fragments' K order changes (packed to match on
+// the host, vtcnn2_bf16_pack_sched).  Bf (that operand) is double-buffered by step parity.
+// K slots of conv1 (16): lanes 0-31 carry k 0..7 = (x_hi s0,s1 | x_lo s0,s1 | x_hi s2,s3 | x_lo s2,s3) against the
+// taps' high halves, lanes 32-63 carry k 8..15 = (x_hi s0,s1 | 1,1 | x_hi s2,s3 | 1,1) against the taps' low halves
+// and the bias (hi, lo): conv1 is accurate to ~2^-16 although every operand is bf16.
+// Image of a 16-frame group: [lane = f + 16h + 32*khalf][140 words]; entry e (2 words) = (bf16 pair e of the padded
+// row: x_hi, then x_lo or (1,1)).  The B operand of an even position is 4 consecutive words (one ds_read_b128 or
+// ds_read2_b64, used as loaded); odd positions start one sample later (4 v_alignbit).  Stride 140 = 4 * odd keeps
+// ds_read_b128 conflict-free.
 // Hazards hipcc would not see inside asm, and how the order guarantees them:
-//   VALU write -> MFMA read (2 wait states): Bf is written a phase before its first reader; the operand words
+//   VALU write -> MFMA read (2 wait states): Bf is written a phase before its first reader; the operand dwords
 //     at least one MFMA before conv1;
-//   MFMA write -> VALU/DS read (<= 18 wait states for these shapes): every reader is >= 2 MFMAs later;
+//   MFMA write -> VALU/DS read: every reader is >= 2 MFMAs (16-cycle shapes) / >= 5 MFMAs (the 32x32 results) later;
 //   an asm MFMA's result lands long after the statement: its destination must stay live until a reader
 //     (a dead destination gets reallocated and clobbered: a "no pack" timing probe faulted that way);
 //   ds_write source vs later MFMA overwrite (not interlocked for XDL writes): a2 is kept alive until after the
 //     barrier's lgkmcnt(0);
+//   compiler-made AGPR copies next to an asm MFMA are not padded (see the accumulator init in the kernel): every
+//     AGPR this kernel's MFMAs read is written by asm only;
 //   the same for a global_store: hipcc gave the data and address registers of a feature store, dead after it, to
 //     the conv1 MFMA that followed it (seen in the ISA; wrong features now and then).  Stores and anything else whose
 //     VGPR operands die at the instruction sit where only AGPR-writing MFMAs follow (T1), never in T2's tail or C1.
 // ------------------------------------------------------------------------------------
-constexpr int kNV = 28;                   // conv2 fragments kept in VGPRs; the other 32 live in AGPRs
-constexpr int kS = 70;                    // image words per lane row: pairs 0..67 (66, 67 zero) + 2 pad
-constexpr int kSImgWords = 2 * 64 * kS;   // [row][lane][kS] per buffer
+constexpr int kNV = 24;                   // conv2 fragments kept in VGPRs; the other 36 live in AGPRs
+constexpr int kS = 140;                   // image words per lane: entries 0..67 (66, 67 zero) + 4 pad
+constexpr int kSImgWords = 64 * kS;       // [lane][kS] per buffer
 constexpr size_t kSchedLds = (size_t)2 * kSImgWords * 4 + (size_t)2 * kPartFloats * 4;      // 112,640 B
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct SchedState {
     u32x4 Wv[kNV];
     u32x4 Wa[kWFrags - kNV];
     f32x4 bias[5];            // conv2 bias tiles as the C operand of the fresh MFMAs (wave 0; zeros on waves 1-3)
-    u32x2 A1[4];
-    unsigned Bf[2][2][2][4];  // [step parity][row][channel pair][word]: B operands of conv2, as scalars
-    f32x4 X[4][2];
+    u32x4 A1[2];              // conv1 A operands: 32 channels x 16 k-slots each
+    unsigned Bf[2][2][2][4];  // [step parity][channel block ct][half bb][word]: B operands of conv2, as scalars
+    f32x16 X[2];              // conv1 results [channel block]
     f32x4 rp[4];
     float rc[4];
-    u32x2 P[3][2];            // operand chunks [slot][row]: chunk c has pairs (2c, 2c+1) in slot c%3, (2c+2, 2c+3) in (c+1)%3
-    unsigned cb[2][2];        // conv1 B operand words [row][word] when they are not a chunk half as it is
+    u32x4 L0[3];              // conv1 operand words, entries (2c, 2c+1) of chunk c = position>>2, slot c%3
+    u32x4 L1;                 // entries (2c+1, 2c+2)
+    unsigned cb[4];           // B operand dwords of an odd position (v_alignbit results)
     unsigned wr_addr, rd_addr, rc_addr, im_addr;    // LDS byte addresses (lane part)
     int gs;                                         // finishing role of this lane: channel chunk (lane & 3)
 };
 
-// conv2 MFMA number I (0..19) of tap J: row H = 1 - I/10, channel pair CP = (I/5)%2, output tile OT = I%5
+// conv2 MFMA number I (0..19) of tap J: channel block CT = 1 - I/10, half BB = (I/5)%2, output tile OT = I%5
 template <int SP, int J, int I>
 __device__ __forceinline__ void sch_tap(SchedState& st, f32x4 (&acc)[5]) {
-    constexpr int H = 1 - I / 10, CP = (I / 5) % 2, OT = I % 5;
-    constexpr int IDX = ((H * 3 + J) * 2 + CP) * 5 + OT;
-    const u32x4 b = u32x4{st.Bf[SP][H][CP][0], st.Bf[SP][H][CP][1], st.Bf[SP][H][CP][2], st.Bf[SP][H][CP][3]};
+    constexpr int CT = 1 - I / 10, BB = (I / 5) % 2, OT = I % 5;
+    constexpr int IDX = ((CT * 3 + J) * 2 + BB) * 5 + OT;
+    const u32x4 b = u32x4{st.Bf[SP][CT][BB][0], st.Bf[SP][CT][BB][1], st.Bf[SP][CT][BB][2], st.Bf[SP][CT][BB][3]};
     if constexpr (J == 0 && I < 5) {      // first MFMA of output v+2: C = bias (early-clobber: D must not alias an input)
         if constexpr (IDX < kNV) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "a"(st.bias[OT]));
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&a"(acc[OT]) : "a"(st.Wa[IDX - kNV]), "v"(b), "a"(st.bias[OT]));
@@ -81,48 +93,48 @@ __device__ __forceinline__ void sch_tap(SchedState& st, f32x4 (&acc)[5]) {
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kNV]), "v"(b));
     }
 }
-// pack instruction N (0..31) of conv1's X into Bf[SP]: unit k = N>>1 = (row, channel pair, tile, half);
-// even N = v_cvt_pk_bf16_f32 of two channels, odd N = ReLU on the packed pair (negative bf16 <=> negative int16).
-// Unit k reads the result of conv1 MFMA number k>>1.
+// pack instruction N (0..31) of conv1's X into Bf[SP]: unit u = N>>1 = (channel block ct, result register pair j);
+// even N = v_cvt_pk_bf16_f32 of two channels, odd N = ReLU on the packed pair (negative bf16 <=> negative int16)
 template <int SP, int N>
 __device__ __forceinline__ void sch_packop(SchedState& st) {
-    constexpr int k = N >> 1, H = k >> 3, CP = (k >> 2) & 1, T = (k >> 1) & 1, HALF = k & 1;
-    unsigned& d = st.Bf[SP][H][CP][2 * T + HALF];
+    constexpr int u = N >> 1, CT = u >> 3, j = u & 7;
+    unsigned& d = st.Bf[SP][CT][j >> 2][j & 3];
     if constexpr ((N & 1) == 0) {
-        const float lo = st.X[2 * CP + T][H][2 * HALF], hi = st.X[2 * CP + T][H][2 * HALF + 1];
+        const float lo = st.X[CT][2 * j], hi = st.X[CT][2 * j + 1];
         asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
     } else {
         asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(d));
     }
 }
-// operand chunk half: pairs (pair0, pair0+1) of row H into slot SLOT; chunk_addr = im_addr + 4*pair0
-template <int SLOT, int H>
-__device__ __forceinline__ void sch_chunk_load(SchedState& st, unsigned chunk_addr) {
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(st.P[SLOT][H]) : "v"(chunk_addr), "i"(H * 64 * kS * 4) : "memory");
+// conv1 operand words: entries (e, e+1) of the image (16-B aligned when e is even) / entries (e, e+1) at 8-B alignment
+template <int SLOT>
+__device__ __forceinline__ void sch_load_even(SchedState& st, unsigned entry_addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(st.L0[SLOT]) : "v"(entry_addr) : "memory");
 }
-// conv1 B operand of position p (R = p&3, chunk words W0..W3 = slot LO .x .y, slot (LO+1)%3 .x .y), prepared one word
-// per call (I = 2*row + word): R=0 (W0,W1) and R=2 (W1,W2) start on a pair, R=1 / R=3 one sample later (v_alignbit)
-template <int R, int LO, int I>
+__device__ __forceinline__ void sch_load_odd(SchedState& st, unsigned entry_addr) {
+    asm volatile("ds_read2_b64 %0, %1 offset0:0 offset1:1" : "=v"(st.L1) : "v"(entry_addr) : "memory");
+}
+// B operand dword I (0..3) of an odd position p (R = p&3; chunk c = p>>2 in slot S0, chunk c+1 in slot SN): the words
+// of entries i, i+1, i+2 (i = p>>1) shifted by one sample.  Even positions use L0[S0] (R=0) or L1 (R=2) as loaded.
+template <int R, int S0, int SN, int I>
 __device__ __forceinline__ void sch_prep(SchedState& st) {
-    constexpr int H = I >> 1, W = I & 1, HI = (LO + 1) % 3;
-    const unsigned w0 = st.P[LO][H][0], w1 = st.P[LO][H][1], w2 = st.P[HI][H][0], w3 = st.P[HI][H][1];
-    unsigned& d = st.cb[H][W];
-    if constexpr (R == 1) {
-        if constexpr (W == 0) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w1), "v"(w0));
-        else asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w2), "v"(w1));
-    } else if constexpr (R == 3) {
-        if constexpr (W == 0) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w2), "v"(w1));
-        else asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w3), "v"(w2));
-    } else if constexpr (R == 2) {
-        if constexpr (W == 0) asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(w1));
-        else asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(w2));
+    if constexpr (R == 1 || R == 3) {
+        // entries i, i+1, i+2 as (A, B) word pairs: e0 = {w[0], w[1]}, e1 = {w[2], w[3]}, e2 = {w[4], w[5]}
+        const unsigned w0 = R == 1 ? st.L0[S0][0] : st.L1[0], w1 = R == 1 ? st.L0[S0][1] : st.L1[1];
+        const unsigned w2 = R == 1 ? st.L0[S0][2] : st.L1[2], w3 = R == 1 ? st.L0[S0][3] : st.L1[3];
+        const unsigned w4 = R == 1 ? st.L1[2] : st.L0[SN][2], w5 = R == 1 ? st.L1[3] : st.L0[SN][3];
+        unsigned& d = st.cb[I];
+        if constexpr (I == 0) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w2), "v"(w0));
+        else if constexpr (I == 1) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w3), "v"(w1));
+        else if constexpr (I == 2) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w4), "v"(w2));
+        else asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w5), "v"(w3));
     }
 }
-template <int R, int LO, int H, int CT>
+template <int R, int S0, int CT>
 __device__ __forceinline__ void sch_conv1_mfma(SchedState& st) {
-    const u32x2 b = R == 0 ? st.P[LO][H] : u32x2{st.cb[H][0], st.cb[H][1]};
+    const u32x4 b = R == 0 ? st.L0[S0] : R == 2 ? st.L1 : u32x4{st.cb[0], st.cb[1], st.cb[2], st.cb[3]};
     // "=&v": the result must not share registers with an operand
-    asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(st.X[CT][H]) : "v"(st.A1[CT]), "v"(b));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(st.X[CT]) : "v"(st.A1[CT]), "v"(b));
 }
 template <int PB, int OT>
 __device__ __forceinline__ void sch_part_write(SchedState& st, const f32x4& a) {
@@ -146,7 +158,7 @@ __device__ __forceinline__ void sch_red_load(SchedState& st) {
 __device__ __forceinline__ void sch_wait_lds(SchedState& st) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(st.rp[0]), "+v"(st.rp[1]), "+v"(st.rp[2]), "+v"(st.rp[3]), "+v"(st.rc[0]), "+v"(st.rc[1]), "+v"(st.rc[2]),
-                   "+v"(st.rc[3]), "+v"(st.P[0][0]), "+v"(st.P[0][1]), "+v"(st.P[1][0]), "+v"(st.P[1][1]), "+v"(st.P[2][0]), "+v"(st.P[2][1])
+                   "+v"(st.rc[3]), "+v"(st.L0[0]), "+v"(st.L0[1]), "+v"(st.L0[2]), "+v"(st.L1)
                  :: "memory");
 }
 // finish of one output position, one VALU instruction per call (K = 0..20): sum of the 4 partials (the bias is
@@ -187,38 +199,39 @@ __device__ __forceinline__ void sch_store(const FinOut& fo, unsigned short* frow
 // roles (v%3), the role of position v+1 in its operand chunk ((v+1)&3) and the chunk slots (((v+1)>>2)%3).
 // ABL: 0 = product; timing-only probes (tools/ablate_sched.py, -DMDC_ABLATIONS; results wrong; every conv2 MFMA stays):
 //   1 no s_barrier   2 no exchange (ds_writes, barrier, reads)   3 no finish VALU / feature stores
-//   5 no conv1 (operand prep, 8 MFMAs, pack)                      6 all of 2, 3, 5
+//   5 no conv1 (operand prep, 2 MFMAs, pack)                      6 all of 2, 3, 5
 //   7 no feature stores (finish VALU kept)   8 no ds_writes   9 no reads of the partials
-//   10 no pack VALU (conv1 kept)             11 no operand chunk loads / prep
+//   10 no pack VALU (conv1 kept)             11 no operand loads / prep
 template <int V12, bool FIRST, bool LAST, int ABL>
 __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned short* fbase, f32x4 (&acc)[3][5]) {
     constexpr int PAR = V12 & 1, PN = 1 - PAR;
-    constexpr int R1 = (V12 + 1) & 3, LO1 = ((V12 + 1) >> 2) % 3;             // position v+1 in its chunk; slot of its W0,W1
-    constexpr bool kLoad = (V12 & 3) == 1 && !LAST;                           // fetch pairs (2c+4, 2c+5), c = v>>2
-    constexpr int LSLOT = ((V12 >> 2) + 2) % 3;
+    constexpr int R1 = (V12 + 1) & 3, S0 = ((V12 + 1) >> 2) % 3, SN = (S0 + 1) % 3;      // position v+1 in its chunk; slots
+    // operand loads: v = 4c+1 fetches entries (2c+2, 2c+3) = L0 of chunk c+1; v = 4c+3 entries (2c+3, 2c+4) = L1 of chunk c+1
+    constexpr bool kLoadEven = (V12 & 3) == 1 && !LAST, kLoadOdd = (V12 & 3) == 3 && !LAST;
+    constexpr int LSLOT = ((V12 >> 2) + 1) % 3;
     constexpr bool kExch = ABL != 2 && ABL != 6, kFin = ABL != 3 && ABL != 6, kC1 = ABL != 5 && ABL != 6;
     f32x4 (&a2)[5] = acc[V12 % 3];
     f32x4 (&a1)[5] = acc[(V12 + 1) % 3];
     f32x4 (&a0)[5] = acc[(V12 + 2) % 3];
-    const unsigned chunk_addr = st.im_addr + ((v >> 2) * 8 + 16);
+    const unsigned load_addr = st.im_addr + ((v >> 2) * 16 + (kLoadEven ? 16 : 24));      // 8 bytes per entry
     FinTmp ft;
     FinOut fo;
 #define FIN(K) do { if (!FIRST && kFin) sch_fin<K>(st, ft, fo); } while (0)
-#define PREP(I) do { if (!LAST && kC1 && ABL != 11) sch_prep<R1, LO1, I>(st); } while (0)
-#define C1M(H, CT) do { if (!LAST && kC1) sch_conv1_mfma<R1, LO1, H, CT>(st); } while (0)
+#define PREP(I) do { if (!LAST && kC1 && ABL != 11) sch_prep<R1, S0, SN, I>(st); } while (0)
+#define C1M(CT) do { if (!LAST && kC1) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
 #define ST(W) do { if (!FIRST && kFin) { if (ABL == 7) asm volatile("" ::"v"(fo.o0), "v"(fo.o1), "v"(fo.tt)); else sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
 #define WR(OT) do { if (kExch && ABL != 8) sch_part_write<PAR, OT>(st, a2[OT]); } while (0)
 #define PK(N) do { if (!LAST && kC1 && ABL != 10) sch_packop<PN, N>(st); } while (0)
 #define RD(R) do { if (kExch && ABL != 9) sch_red_load1<PAR, R>(st); } while (0)
-#define LD(H) do { if (kLoad && kC1 && ABL != 11) sch_chunk_load<LSLOT, H>(st, chunk_addr); } while (0)
-    // the barrier's lgkmcnt(0) covers the ds_writes of a2, issued >= 30 MFMAs earlier.  a2 stays allocated until
+#define LD() do { if (kC1 && ABL != 11) { if (kLoadEven) sch_load_even<LSLOT>(st, load_addr); else if (kLoadOdd) sch_load_odd(st, load_addr); } } while (0)
+    // the barrier's lgkmcnt(0) covers the ds_writes of a2, issued >= 14 MFMAs earlier.  a2 stays allocated until
     // here (ds_write / XDL hazard above): no MFMA issued before this point can have been given its registers
 #define HANDOFF() do { \
         if (ABL == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         else if (kExch) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
-    sch_wait_lds(st);      // partial(v-1) and any operand chunk: read during T0 of the previous step
-    // ---- T2: tap 2 -> a2 complete.  gaps: finish of output v-1 (F0..F18); conv1 operand words of v+1 ride in the last four
+    sch_wait_lds(st);      // partial(v-1) and any operand words: read during T0 of the previous step
+    // ---- T2: tap 2 -> a2 complete.  gaps: finish of output v-1 (F0..F16); the conv1 operand dwords of v+1 in the last four
     sch_tap<PAR, 2, 0>(st, a2); FIN(0);
     sch_tap<PAR, 2, 1>(st, a2); FIN(1);
     sch_tap<PAR, 2, 2>(st, a2); FIN(2);
@@ -236,45 +249,39 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     sch_tap<PAR, 2, 14>(st, a2); FIN(14);
     sch_tap<PAR, 2, 15>(st, a2); FIN(15);
     sch_tap<PAR, 2, 16>(st, a2); FIN(16); PREP(0);
-    sch_tap<PAR, 2, 17>(st, a2); FIN(17); PREP(1);
-    sch_tap<PAR, 2, 18>(st, a2); FIN(18); PREP(2);
+    sch_tap<PAR, 2, 17>(st, a2); PREP(1);
+    sch_tap<PAR, 2, 18>(st, a2); PREP(2);
     sch_tap<PAR, 2, 19>(st, a2); PREP(3);
-    // ---- C1: conv1(v+1), the only MFMAs that write VGPRs.  gaps: end of the finish, first ds_writes of partial(v)
-    //      (the four waves share the CU's LDS store path, 13 cycles per ds_write_b128: one every third gap keeps it
-    //      unsaturated), first pack ops.  NO feature store here: see the hazard list
-    C1M(0, 0); FIN(19);
-    C1M(0, 1); WR(0);
-    C1M(0, 2); FIN(20);
-    C1M(0, 3); PK(0);
-    C1M(1, 0); WR(1);
-    C1M(1, 1); PK(1);
-    C1M(1, 2); PK(2);
-    C1M(1, 3); WR(2);
-    // ---- T1: tap 1.  gaps: the two feature stores, the last two ds_writes, pack of conv1(v+1) one VALU each
+    // ---- C1: conv1(v+1): two 32x32x16 MFMAs, the only ones that write VGPRs.  Their 32-cycle gaps take two VALU and
+    //      one LDS instruction each: end of the finish, first two ds_writes of partial(v).  NO feature store here (hazards)
+    C1M(0); FIN(17); FIN(18); WR(0);
+    C1M(1); FIN(19); FIN(20); WR(1);
+    // ---- T1: tap 1.  gaps: the two feature stores, three more ds_writes (the four waves share the CU's LDS store path,
+    //      13 cycles per ds_write_b128: one every third gap keeps it unsaturated), pack of conv1(v+1) one VALU each
     sch_tap<PAR, 1, 0>(st, a1); ST(0);
-    sch_tap<PAR, 1, 1>(st, a1); PK(3);
-    sch_tap<PAR, 1, 2>(st, a1); WR(3);
-    sch_tap<PAR, 1, 3>(st, a1); ST(1);
-    sch_tap<PAR, 1, 4>(st, a1); PK(4);
-    sch_tap<PAR, 1, 5>(st, a1); WR(4);
-    sch_tap<PAR, 1, 6>(st, a1); PK(5);
-    sch_tap<PAR, 1, 7>(st, a1); PK(6);
-    sch_tap<PAR, 1, 8>(st, a1); PK(7);
-    sch_tap<PAR, 1, 9>(st, a1); PK(8);
-    sch_tap<PAR, 1, 10>(st, a1); PK(9);
-    sch_tap<PAR, 1, 11>(st, a1); PK(10);
-    sch_tap<PAR, 1, 12>(st, a1); PK(11);
-    sch_tap<PAR, 1, 13>(st, a1); PK(12);
-    sch_tap<PAR, 1, 14>(st, a1); PK(13);
-    sch_tap<PAR, 1, 15>(st, a1); PK(14);
-    sch_tap<PAR, 1, 16>(st, a1); PK(15);
-    sch_tap<PAR, 1, 17>(st, a1); PK(16);
-    sch_tap<PAR, 1, 18>(st, a1); PK(17);
-    sch_tap<PAR, 1, 19>(st, a1); PK(18);
-    // ---- T0: tap 0 (5 fresh).  gaps: chunk loads (every 4th step), hand-off, the 8 reads of partial(v), rest of the pack
-    sch_tap<PAR, 0, 0>(st, a0); PK(19); LD(0);
-    sch_tap<PAR, 0, 1>(st, a0); PK(20); LD(1);
-    sch_tap<PAR, 0, 2>(st, a0); PK(21); HANDOFF();
+    sch_tap<PAR, 1, 1>(st, a1); WR(2);
+    sch_tap<PAR, 1, 2>(st, a1); ST(1);
+    sch_tap<PAR, 1, 3>(st, a1); PK(0);
+    sch_tap<PAR, 1, 4>(st, a1); WR(3);
+    sch_tap<PAR, 1, 5>(st, a1); PK(1);
+    sch_tap<PAR, 1, 6>(st, a1); PK(2);
+    sch_tap<PAR, 1, 7>(st, a1); WR(4);
+    sch_tap<PAR, 1, 8>(st, a1); PK(3);
+    sch_tap<PAR, 1, 9>(st, a1); PK(4);
+    sch_tap<PAR, 1, 10>(st, a1); PK(5);
+    sch_tap<PAR, 1, 11>(st, a1); PK(6);
+    sch_tap<PAR, 1, 12>(st, a1); PK(7);
+    sch_tap<PAR, 1, 13>(st, a1); PK(8);
+    sch_tap<PAR, 1, 14>(st, a1); PK(9);
+    sch_tap<PAR, 1, 15>(st, a1); PK(10);
+    sch_tap<PAR, 1, 16>(st, a1); PK(11);
+    sch_tap<PAR, 1, 17>(st, a1); PK(12);
+    sch_tap<PAR, 1, 18>(st, a1); PK(13);
+    sch_tap<PAR, 1, 19>(st, a1); PK(14);
+    // ---- T0: tap 0 (5 fresh).  gaps: operand load (every 2nd step), hand-off, the 8 reads of partial(v), rest of the pack
+    sch_tap<PAR, 0, 0>(st, a0); PK(15); LD();
+    sch_tap<PAR, 0, 1>(st, a0); PK(16);
+    sch_tap<PAR, 0, 2>(st, a0); PK(17); HANDOFF();
     sch_tap<PAR, 0, 3>(st, a0); RD(0);
     sch_tap<PAR, 0, 4>(st, a0); RD(1);
     sch_tap<PAR, 0, 5>(st, a0); RD(2);
@@ -283,20 +290,16 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     sch_tap<PAR, 0, 8>(st, a0); RD(5);
     sch_tap<PAR, 0, 9>(st, a0); RD(6);
     sch_tap<PAR, 0, 10>(st, a0); RD(7);
-    sch_tap<PAR, 0, 11>(st, a0); PK(22);
-    sch_tap<PAR, 0, 12>(st, a0); PK(23);
-    sch_tap<PAR, 0, 13>(st, a0); PK(24);
-    sch_tap<PAR, 0, 14>(st, a0); PK(25);
-    sch_tap<PAR, 0, 15>(st, a0); PK(26);
-    sch_tap<PAR, 0, 16>(st, a0); PK(27);
-    sch_tap<PAR, 0, 17>(st, a0); PK(28);
-    sch_tap<PAR, 0, 18>(st, a0); PK(29);
-    sch_tap<PAR, 0, 19>(st, a0); PK(30); PK(31);
-    if (ABL == 10 && !LAST) {      // probe 10: the conv1 results must stay live up to here (async MFMA write)
-        f32x4 &x0 = st.X[0][1], &x1 = st.X[1][1], &x2 = st.X[2][1], &x3 = st.X[3][1];
-        f32x4 &y0 = st.X[0][0], &y1 = st.X[1][0], &y2 = st.X[2][0], &y3 = st.X[3][0];
-        asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y0), "v"(y1), "v"(y2), "v"(y3));
-    }
+    sch_tap<PAR, 0, 11>(st, a0); PK(18); PK(19);
+    sch_tap<PAR, 0, 12>(st, a0); PK(20); PK(21);
+    sch_tap<PAR, 0, 13>(st, a0); PK(22); PK(23);
+    sch_tap<PAR, 0, 14>(st, a0); PK(24); PK(25);
+    sch_tap<PAR, 0, 15>(st, a0); PK(26); PK(27);
+    sch_tap<PAR, 0, 16>(st, a0); PK(28);
+    sch_tap<PAR, 0, 17>(st, a0); PK(29);
+    sch_tap<PAR, 0, 18>(st, a0); PK(30);
+    sch_tap<PAR, 0, 19>(st, a0); PK(31);
+    if (ABL == 10 && !LAST) asm volatile("" ::"v"(st.X[0]), "v"(st.X[1]));      // probe 10: conv1 results stay live (async MFMA write)
 #undef FIN
 #undef PREP
 #undef C1M
@@ -321,16 +324,15 @@ __device__ __forceinline__ void sch_stage_write(int k, float4 v, long n, long fr
         const unsigned hi = pack2(a, b);
         const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
         const unsigned lo = pack2(a - ah, b - bh);
-        unsigned* d = im + (h * 64 + i) * kS + 2 * m + 1 + e;      // samples 4m+2e, +1 -> padded 4m+2e+2, +3
-        d[0] = hi;                // k-group 0: x hi
-        d[16 * kS] = lo;          // k-group 1: x lo
-        d[32 * kS] = hi;          // k-group 2: x hi again (meets the low halves of the taps)
+        unsigned* d = im + (i + 16 * h) * kS + 2 * (2 * m + 1 + e);      // samples 4m+2e, +1 -> padded pair 2m+1+e
+        *reinterpret_cast<u32x2*>(d) = u32x2{hi, lo};      // lower k-half: (x_hi, x_lo)
+        d[32 * kS] = hi;                                   // upper k-half: x_hi (its second word stays (1,1))
     }
 }
 
 template <int ABL>
 __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float* __restrict__ x, long n,
-                                                                    const u32x4* __restrict__ wq, const u32x2* __restrict__ a1q,
+                                                                    const u32x4* __restrict__ wq, const u32x4* __restrict__ a1q,
                                                                     const float* __restrict__ b2, unsigned short* __restrict__ feat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* img = reinterpret_cast<unsigned*>(smem);
@@ -345,8 +347,8 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
         if (i < kNV) { st.Wv[i] = w; asm volatile("" : "+v"(st.Wv[i])); }
         else { st.Wa[i - kNV] = w; asm volatile("" : "+a"(st.Wa[i - kNV])); }
     }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) st.A1[ct] = a1q[(q * 4 + ct) * 64 + lane];
+    st.A1[0] = a1q[(q * 2 + 0) * 64 + lane];
+    st.A1[1] = a1q[(q * 2 + 1) * 64 + lane];
     // accumulator rows of tile ot on this lane = output channels 16*ot + 4g .. +3
 #pragma unroll
     for (int ot = 0; ot < 5; ++ot) {
@@ -368,11 +370,13 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
 #pragma unroll
     for (int k = 0; k < 4; ++k) { st.rp[k] = f32x4{0.f, 0.f, 0.f, 0.f}; st.rc[k] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) { st.P[s][0] = u32x2{0u, 0u}; st.P[s][1] = u32x2{0u, 0u}; }
-    st.cb[0][0] = st.cb[0][1] = st.cb[1][0] = st.cb[1][1] = 0u;
+    for (int s = 0; s < 3; ++s) st.L0[s] = u32x4{0u, 0u, 0u, 0u};
+    st.L1 = u32x4{0u, 0u, 0u, 0u};
+    st.cb[0] = st.cb[1] = st.cb[2] = st.cb[3] = 0u;
 
-    // LDS init: zero padding pairs; the k-group-3 lanes (48..63) hold the constant (1,1) of the bias slots
-    for (int i = tid; i < 2 * kSImgWords; i += 256) img[i] = (((i / kS) & 63) >= 48) ? 0x3F803F80u : 0u;
+    // LDS init: zero padding entries; the second word of every entry of the upper-k-half lanes (32..63) is the
+    // constant (1,1) that meets the conv1 bias
+    for (int i = tid; i < 2 * kSImgWords; i += 256) img[i] = ((((i / kS) & 63) >= 32) && ((i % kS) & 1)) ? 0x3F803F80u : 0u;
     __syncthreads();
     const long ngroups = (n + 15) >> 4;
     long grp = blockIdx.x;
@@ -385,22 +389,26 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
         st.im_addr = img_lds + (buf * kSImgWords + lane * kS) * 4;
         unsigned short* fbase = feat + (grp * 16 + fs) * (long)(kW2 * kC2);
         const long gnext = grp + gridDim.x;
-        // outputs 0 and 1 never see a fresh MFMA: they start from the bias; acc[2] is step 0's fresh accumulator
+        // outputs 0 and 1 never see a fresh MFMA: they start from the bias; acc[2] is step 0's fresh accumulator.
+        // The copy is an MFMA (0 x 0 + bias), not `acc = bias`: hipcc turned the assignment into v_accvgpr_mov
+        // instructions and sank two of them right in front of the asm MFMA that reads those AGPRs as its C operand
+        // -- a VALU-write -> MFMA-read hazard it pads for its own MFMAs but not for asm (wrong output 1, now and then).
         f32x4 acc[3][5];
-#pragma unroll
-        for (int b = 0; b < 5; ++b) { acc[0][b] = st.bias[b]; acc[1][b] = st.bias[b]; acc[2][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-        // prologue: chunk 0 (pairs 0..3), conv1 of position 0 packed into Bf[0]
-        sch_chunk_load<0, 0>(st, st.im_addr); sch_chunk_load<0, 1>(st, st.im_addr);
-        sch_chunk_load<1, 0>(st, st.im_addr + 8); sch_chunk_load<1, 1>(st, st.im_addr + 8);
-        sch_wait_lds(st);
-        sch_conv1_mfma<0, 0, 0, 0>(st); sch_conv1_mfma<0, 0, 0, 1>(st); sch_conv1_mfma<0, 0, 0, 2>(st); sch_conv1_mfma<0, 0, 0, 3>(st);
-        sch_conv1_mfma<0, 0, 1, 0>(st); sch_conv1_mfma<0, 0, 1, 1>(st); sch_conv1_mfma<0, 0, 1, 2>(st); sch_conv1_mfma<0, 0, 1, 3>(st);
         {
-            f32x4 &x0 = st.X[0][1], &x1 = st.X[1][1], &x2 = st.X[2][1], &x3 = st.X[3][1];
-            f32x4 &y0 = st.X[0][0], &y1 = st.X[1][0], &y2 = st.X[2][0], &y3 = st.X[3][0];
-            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+            const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %1, %2" : "=&a"(acc[0][b]) : "v"(zero), "a"(st.bias[b]));
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %2" : "=&a"(acc[1][b]) : "v"(zero), "a"(st.bias[b]));
+            }
         }
+
+        // prologue: entries 0..2, conv1 of position 0 packed into Bf[0]
+        sch_load_even<0>(st, st.im_addr);
+        sch_load_odd(st, st.im_addr + 8);
+        sch_wait_lds(st);
+        sch_conv1_mfma<0, 0, 0>(st); sch_conv1_mfma<0, 0, 1>(st);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(st.X[0]), "+v"(st.X[1]));
         [&]<int... N>(std::integer_sequence<int, N...>) { (sch_packop<0, N>(st), ...); }(std::make_integer_sequence<int, 32>{});
         asm volatile("s_nop 1");
 
@@ -463,13 +471,60 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
 
 }  // namespace
 
+// Operands of this kernel (d_pack slots 6 and 7).
+//   conv2 A fragments [q][((ct*3+j)*2+bb)*5+ot][lane][8]: lane (o' = lane&15, kg = lane>>4), slot jj holds
+//     K2[16ot+o'][64q + 32ct + 8*(r>>2) + 4*(kg>>1) + (r&3)][h = kg&1][j],  r = 8bb + jj
+//     -- the K order in which conv1's 32x32 result arrives (C/D layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
+//     column = lane&31 = frame + 16*row h of the I/Q pair)
+//   conv1 A operands [q][ct][lane][8]: lane (m = lane&31, khalf = lane>>5) = channel 64q + 32ct + m; slots as in the
+//     kernel header: khalf 0 (t0h,t1h | t0h,t1h | t2h,0 | t2h,0), khalf 1 (t0l,t1l | b_hi,b_lo | t2l,0 | 0,0)
+int vtcnn2_bf16_pack_sched(mdc_model* m) {
+    const float* k1 = m->hk[0].data();   // (256,1,1,3)
+    const float* b1 = m->hb[0].data();
+    const float* k2 = m->hk[1].data();   // (80,256,2,3)
+    int rc;
+    std::vector<unsigned short> wq((size_t)4 * kWFrags * 64 * 8);
+    for (int q = 0; q < 4; ++q)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int j = 0; j < 3; ++j)
+                for (int bb = 0; bb < 2; ++bb)
+                    for (int ot = 0; ot < 5; ++ot)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int jj = 0; jj < 8; ++jj) {
+                                const int o = 16 * ot + (lane & 15), kg = lane >> 4, h = kg & 1, r = 8 * bb + jj;
+                                const int ch = 64 * q + 32 * ct + 8 * (r >> 2) + 4 * (kg >> 1) + (r & 3);
+                                const size_t idx = ((((size_t)q * kWFrags + ((ct * 3 + j) * 2 + bb) * 5 + ot) * 64) + lane) * 8 + jj;
+                                wq[idx] = f2bf(k2[(((size_t)o * kC1 + ch) * 2 + h) * 3 + j]);
+                            }
+    if ((rc = upload(m, 6, wq.data(), wq.size() * 2))) return rc;
+    std::vector<unsigned short> a1((size_t)4 * 2 * 64 * 8, 0);
+    for (int q = 0; q < 4; ++q)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = 64 * q + 32 * ct + (lane & 31), khalf = lane >> 5;
+                unsigned short* d = &a1[(((size_t)q * 2 + ct) * 64 + lane) * 8];
+                unsigned short th[3], tl[3];
+                for (int t = 0; t < 3; ++t) {
+                    th[t] = f2bf(k1[ch * 3 + t]);
+                    tl[t] = f2bf(k1[ch * 3 + t] - bf2f(th[t]));
+                }
+                if (khalf == 0) {
+                    d[0] = th[0]; d[1] = th[1]; d[2] = th[0]; d[3] = th[1]; d[4] = th[2]; d[6] = th[2];
+                } else {
+                    const unsigned short bh = f2bf(b1[ch]);
+                    d[0] = tl[0]; d[1] = tl[1]; d[2] = bh; d[3] = f2bf(b1[ch] - bf2f(bh)); d[4] = tl[2];
+                }
+            }
+    return upload(m, 7, a1.data(), a1.size() * 2);
+}
+
 int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define MDC_LAUNCH_SCHED(A) do { \
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_sched_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
     hipLaunchKernelGGL(vt_conv_bf16_sched_kernel<A>, dim3(grid), dim3(256), kSchedLds, s, x, (long)n, \
-                       static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]), \
+                       static_cast<const u32x4*>(m->d_pack[6]), static_cast<const u32x4*>(m->d_pack[7]), \
                        static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat)); } while (0)
 #ifdef MDC_ABLATIONS   // timing-only variants for tools/ablate_sched.py (build with -DMDC_ABLATIONS); results are wrong
     static const int abl = getenv("MDC_ABLATE_S") ? atoi(getenv("MDC_ABLATE_S")) : 0;

@@ -29,5 +29,7 @@ def test_lint_flags_the_pattern():
     assert len(lint.lint(bad)) == 1
     ok = ["global_store_dwordx2 v[136:137], v[134:135], off", "v_mfma_f32_16x16x32_bf16 a[0:3], v[164:167], v[176:179], a[0:3]"]
     assert lint.lint(ok) == []
+    mov = ["v_accvgpr_mov_b32 a200, a160", "v_mfma_f32_16x16x32_bf16 a[200:203], a[80:83], v[180:183], a[200:203]"]
+    assert len(lint.lint(mov)) == 1
     waited = ["ds_write_b128 v10, v[20:23]", "s_waitcnt lgkmcnt(0)", "v_mfma_f32_16x16x16_bf16 v[20:23], v[1:2], v[3:4], 0"]
     assert lint.lint(waited) == []

@@ -7,6 +7,10 @@ global_store / ds_write to a following VGPR-writing MFMA, the store can go out w
 address, too.  The hardware interlocks VALU writes, not XDL writes.  Seen once in this kernel: the feature store
 of a step was followed by the first conv1 MFMA, whose destination was the store's data+address registers.
 
+A second pattern of the same family: hipcc implements `acc = bias` (AGPR to AGPR) with v_accvgpr_mov and may
+sink such a move right in front of an asm MFMA that reads the AGPR as its C operand; it pads that VALU-write ->
+MFMA-read hazard for its own MFMAs only.
+
 The lint disassembles the kernel and reports every store-like instruction whose VGPR sources overlap the
 destination of a VGPR-writing MFMA issued within WINDOW instructions after it, unless an s_waitcnt that covers the
 memory instruction (lgkmcnt(0) for DS) sits between them.  Exit status 1 if any is found.
@@ -55,6 +59,18 @@ def kernel_isa(src, kernel):
 
 def lint(isa):
     found = []
+    # (b) a VALU write (hipcc pads v_accvgpr_mov/write -> MFMA only for its own MFMAs, not for asm ones) of a register
+    #     that one of the next two instructions, an MFMA, reads
+    for i, ins in enumerate(isa):
+        if ins.startswith(("v_accvgpr_mov", "v_accvgpr_write")):
+            dst = ins.split()[1].rstrip(",")
+            for j in range(i + 1, min(i + 3, len(isa))):
+                if isa[j].startswith("v_mfma") and re.search(r"\ba\[(\d+):(\d+)\]", isa[j]):
+                    n = int(dst[1:])
+                    for m in re.finditer(r"\ba\[(\d+):(\d+)\]", isa[j].split(",", 1)[1]):
+                        if int(m.group(1)) <= n <= int(m.group(2)):
+                            found.append((i, ins, isa[j]))
+    # (a) store-like instruction vs a following VGPR-writing MFMA
     for i, ins in enumerate(isa):
         if ins.startswith(("global_store", "ds_write", "buffer_store", "scratch_store")):
             src = vregs(ins)

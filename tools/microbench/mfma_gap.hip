@@ -14,7 +14,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int kIters = 2000;
 constexpr int kMfmaPerIter = 20;
 
-template <int F, bool A_IN_AGPR, bool SMALL = false>
+template <int F, bool A_IN_AGPR, int SMALL = 0>
 __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, float* sink) {
     __shared__ __attribute__((aligned(16))) float lds[4096];
     const int lane = threadIdx.x & 63;
@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     asm volatile("" : "+a"(wa));
     asm volatile("" : "+v"(wv));
     f32x4 xs[8];
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    f32x16 xl[2];
     f32x2 a16 = f32x2{1.f, 1.f}, b16 = f32x2{1.f, 1.f};
     asm volatile("" : "+v"(a16), "+v"(b16));
     f32x2 p0 = f32x2{1.f, 2.f}, p1 = f32x2{3.f, 4.f}, p2, p3;
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
         for (int m = 0; m < kMfmaPerIter; ++m) {
-            if (SMALL) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xs[m % 8]) : "v"(a16), "v"(b16));
+            if (SMALL == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(xl[m % 2]) : "v"(wv), "v"(b));
+            else if (SMALL) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xs[m % 8]) : "v"(a16), "v"(b16));
             else if (A_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m % 5]) : "a"(wa), "v"(b));
             else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m % 5]) : "v"(wv), "v"(b));
             if (F == 1 || F == 2) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p2) : "v"(p0), "v"(p1));
@@ -100,12 +103,13 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     asm volatile("" ::"v"(p2), "v"(p3), "v"(c0), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(r0), "v"(r1), "v"(u64a));
     float keep = 0.f;
     for (int i = 0; i < 5; ++i) keep += acc[i][0];
-    if (SMALL) for (int i = 0; i < 8; ++i) { asm volatile("s_nop 7" : "+v"(xs[i])); keep += xs[i][0]; }
+    if (SMALL == 1) for (int i = 0; i < 8; ++i) { asm volatile("s_nop 7" : "+v"(xs[i])); keep += xs[i][0]; }
+    if (SMALL == 2) for (int i = 0; i < 2; ++i) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(xl[i])); keep += xl[i][0]; }
     if (keep == 123.456f) sink[0] = keep;
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
 
-template <int F, bool A, bool SMALL = false>
+template <int F, bool A, int SMALL = 0>
 static void run(const char* name, unsigned long long* d_out, float* d_sink) {
     hipLaunchKernelGGL((gap_kernel<F, A, SMALL>), dim3(256), dim3(256), 0, 0, d_out, d_sink);      // warm
     hipEvent_t e0, e1;
@@ -164,10 +168,16 @@ int main() {
     run<34, true>("store short alone per 20 MFMAs", d_out, d_sink);
     run<32, true>("store x2 + dword(dup lanes) per 20 MFMAs", d_out, d_sink);
     run<35, true>("store dwordx4 per 20 MFMAs", d_out, d_sink);
-    run<0, true, true>("16x16x16: none", d_out, d_sink);
-    run<5, true, true>("16x16x16: 1 v_add_f32 per gap", d_out, d_sink);
-    run<6, true, true>("16x16x16: 2 v_add_f32 per gap", d_out, d_sink);
-    run<20, true, true>("16x16x16: 1 v_pk_max_i16 per gap", d_out, d_sink);
-    run<8, true, true>("16x16x16: 1 ds_read_b128 per gap", d_out, d_sink);
+    run<0, true, 1>("16x16x16: none", d_out, d_sink);
+    run<5, true, 1>("16x16x16: 1 v_add_f32 per gap", d_out, d_sink);
+    run<6, true, 1>("16x16x16: 2 v_add_f32 per gap", d_out, d_sink);
+    run<20, true, 1>("16x16x16: 1 v_pk_max_i16 per gap", d_out, d_sink);
+    run<8, true, 1>("16x16x16: 1 ds_read_b128 per gap", d_out, d_sink);
+    run<0, true, 2>("32x32x16 (VGPR dst): none", d_out, d_sink);
+    run<5, true, 2>("32x32x16: 1 v_add_f32 per gap", d_out, d_sink);
+    run<6, true, 2>("32x32x16: 2 v_add_f32 per gap", d_out, d_sink);
+    run<7, true, 2>("32x32x16: 4 v_add_f32 per gap", d_out, d_sink);
+    run<8, true, 2>("32x32x16: 1 ds_read_b128 per gap", d_out, d_sink);
+    run<21, true, 2>("32x32x16: v_add + ds_read_b128 per gap", d_out, d_sink);
     return 0;
 }
