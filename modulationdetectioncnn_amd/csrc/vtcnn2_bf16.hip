@@ -329,13 +329,15 @@ int vtcnn2_bf16_pack(mdc_model* m) {
                 }
             }
     if ((rc = upload(m, 1, a1.data(), a1.size() * 2))) return rc;
-    // dense1: transposed [n][k'] with k' = w*80 + o  <-  reference row o*132 + w
+    // dense1: transposed and K-tiled [k'/64][n][k'%64] with k' = w*80 + o  <-  reference row o*132 + w
     const float* w1 = m->hk[2].data();
     std::vector<unsigned short> w1t((size_t)kHid * kFeat);
     for (int w = 0; w < kW2; ++w)
         for (int o = 0; o < kC2; ++o) {
             const float* src = w1 + (size_t)(o * kW2 + w) * kHid;
-            for (int nn = 0; nn < kHid; ++nn) w1t[(size_t)nn * kFeat + (w * kC2 + o)] = f2bf(src[nn]);
+            // tile-contiguous: [k-tile of 64][hidden unit][64], so a K-tile of the GEMM's B operand is one 32 KiB block
+            const int kk = w * kC2 + o;
+            for (int nn = 0; nn < kHid; ++nn) w1t[((size_t)(kk >> 6) * kHid + nn) * 64 + (kk & 63)] = f2bf(src[nn]);
         }
     if ((rc = upload(m, 3, w1t.data(), w1t.size() * 2))) return rc;
     return vtcnn2_bf16_pack_sched(m);      // operands of the asm-sequenced conv kernel (its own K order)

@@ -25,7 +25,7 @@ constexpr int kNT = kFeat / kBK;                              // 165 K-tiles
 
 template <int ABL>   // 0 = product; 1..3 = timing-only probes (tools/ablate_dense1.py, -DMDC_ABLATIONS; results wrong)
 __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned short* __restrict__ feat, long n,
-                                                             const unsigned short* __restrict__ w1t,   // [256][10560] bf16
+                                                             const unsigned short* __restrict__ w1t,   // [165 k-tiles][256][64] bf16
                                                              const float* __restrict__ c1,
                                                              float* __restrict__ hid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned shor
         long gr = (ABL == 1 ? 0 : row0) + r;                // probe 1: every work-group streams the same rows (L2 hits)
         if (gr >= n) gr = n - 1;                            // clamp: rows past the end are computed, not stored
         asrc[p] = feat + gr * (long)kFeat + ((spos ^ (r & 7)) * 8);
-        bsrc[p] = w1t + (long)r * kFeat + ((spos ^ (r & 7)) * 8);
+        bsrc[p] = w1t + r * kBK + ((spos ^ (r & 7)) * 8);
     }
     auto stage = [&](int t, int b) {
         if (ABL == 3 && t > 1) return;                      // probe 3: no staging traffic (compute on stale tiles)
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned shor
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             glds16(asrc[p] + t * kBK, A + (wv * 4 + p) * 1024);
-            glds16(bsrc[p] + t * kBK, B + (wv * 4 + p) * 1024);
+            glds16(bsrc[p] + (long)t * (kBN * kBK), B + (wv * 4 + p) * 1024);
         }
     };
 
