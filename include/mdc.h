@@ -105,6 +105,28 @@ int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n,
                 void* workspace_dev, size_t workspace_bytes,
                 void* hip_stream);
 
+/* ---- callers either side of the forward -------------------------------------------
+
+ * Q6.12 integer forward of a DEPLOYED model: the arithmetic of the reference's FPGA datapath
+ * (cnn_test_latest1.sv:642-675 bit selections, 18-bit wrap, 32-bit dense accumulators, sv:293-343, 171-176), for
+ * validating ROM tables / test vectors written by the float2fix exporter (CNN.ipynb cells 23-24).  The integer
+ * tables are made from the model's weights at mdc_finalize (float2fix: trunc(v * 4096)).
+ * x_dev: (n,2,128) f32 frames (quantised on load, x_is_q612 = 0) or int32 Q6.12 words (x_is_q612 = 1).
+ * dense_dev (n,C) int32 = post-ReLU class sums, value/4096 (or NULL); labels_dev (n) int32 first maximum (or NULL). */
+int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64_t n,
+                     int32_t* dense_dev, int32_t* labels_dev, void* hip_stream);
+
+/* Confusion counts of cnn.py:205-216 / 242-255 on the device: counts_dev[t*classes + p] += 1 for every i with
+ * truth_dev[i] == t and pred_dev[i] == p (int64, caller-zeroed, accumulates across calls).  Pairs with a label
+ * outside [0,classes) are added to *bad_dev instead (may be NULL).  classes <= 32.  Runs on the current device. */
+int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, int classes,
+                  int64_t* counts_dev, int64_t* bad_dev, void* hip_stream);
+
+/* Raw SDR bytes -> frames: iq_dev holds n frames of 128 interleaved unsigned 8-bit (I,Q) pairs (256 B/frame, the
+ * RTL-SDR format of the front-end in the reference's README.md:5); x_dev (n,2,128) f32 receives
+ * ((byte - 127.5) * scale) with I in row 0 and Q in row 1.  Runs on the current device. */
+int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream);
+
 /* Measurement support (bench.py roofline leg): when on, mdc_forward brackets each kernel
  * launch with HIP events on the launch stream; mdc_profile_read synchronises on them and
  * returns the summed device time and launch count of kernel slot `slot` since the last

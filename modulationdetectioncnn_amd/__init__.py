@@ -3,5 +3,6 @@ peteroh23/ModulationDetectionCNN.  Product code: formats + host 
 libmdc.so (HIP).  The CPU oracle lives in /oracle and is never imported from here."""
 from .topology import Topology, synthetic_weights, synthetic_frames  # noqa: F401
 from .model import VTCNN2  # noqa: F401
+from .frontend import frames_from_iq_u8  # noqa: F401
 
-__all__ = ["Topology", "VTCNN2", "synthetic_weights", "synthetic_frames"]
+__all__ = ["Topology", "VTCNN2", "synthetic_weights", "synthetic_frames", "frames_from_iq_u8"]

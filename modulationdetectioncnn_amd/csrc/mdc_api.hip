@@ -163,7 +163,7 @@ int mdc_finalize(mdc_model* m, int dtype) {
     MDC_HIP(hipSetDevice(m->device));
     int rc;
     switch (m->topo.kind) {
-        case MDC_KIND_DEPLOYED: rc = deployed_pack(m); break;
+        case MDC_KIND_DEPLOYED: rc = deployed_pack(m); if (rc == MDC_OK) rc = deployed_q612_pack(m); break;
         case MDC_KIND_VTCNN2:   rc = vtcnn2_pack(m); break;
         case MDC_KIND_CNNPY:    rc = cnnpy_pack(m); break;
         default: rc = MDC_EINVAL;
@@ -207,6 +207,41 @@ int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n, float* probs_d
     }
     if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
     return rc;
+}
+
+int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64_t n, int32_t* dense_dev, int32_t* labels_dev,
+                     void* hip_stream) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    if (!m->finalized) { set_error("mdc_forward_q612: model not finalized"); return MDC_ESTATE; }
+    if (m->topo.kind != MDC_KIND_DEPLOYED) { set_error("mdc_forward_q612: the FPGA datapath exists for the deployed nets only"); return MDC_ENOTSUP; }
+    if (n < 0) { set_error("mdc_forward_q612: negative frame count"); return MDC_EINVAL; }
+    if (n == 0) return MDC_OK;
+    if (!x_dev) { set_error("mdc_forward_q612: null input"); return MDC_EINVAL; }
+    int cur = -1;
+    MDC_HIP(hipGetDevice(&cur));
+    if (cur != m->device) MDC_HIP(hipSetDevice(m->device));
+    const int rc = deployed_q612_forward(m, x_dev, x_is_q612 != 0, n, dense_dev, labels_dev, static_cast<hipStream_t>(hip_stream));
+    if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
+    return rc;
+}
+
+int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, int classes, int64_t* counts_dev, int64_t* bad_dev,
+                  void* hip_stream) {
+    if (n < 0) { set_error("mdc_confusion: negative count"); return MDC_EINVAL; }
+    if (n > 0 && (!truth_dev || !pred_dev)) { set_error("mdc_confusion: null labels"); return MDC_EINVAL; }
+    if (!counts_dev) { set_error("mdc_confusion: null counts"); return MDC_EINVAL; }
+    return confusion_launch(truth_dev, pred_dev, n, classes, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream));
+}
+
+int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream) {
+    if (n < 0) { set_error("mdc_iq_u8_to_frames: negative frame count"); return MDC_EINVAL; }
+    if (n == 0) return MDC_OK;
+    if (!iq_dev || !x_dev) { set_error("mdc_iq_u8_to_frames: null buffer"); return MDC_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(iq_dev) & 3) != 0 || (reinterpret_cast<uintptr_t>(x_dev) & 7) != 0) {
+        set_error("mdc_iq_u8_to_frames: iq must be 4-byte and frames 8-byte aligned");
+        return MDC_EINVAL;
+    }
+    return iq_u8_launch(iq_dev, n, scale, x_dev, static_cast<hipStream_t>(hip_stream));
 }
 
 int mdc_set_profiling(mdc_model* m, int on) {

@@ -77,6 +77,12 @@ int upload(mdc_model* m, int idx, const void* host, size_t bytes);
 
 // ---- deployed (T1/T2): deployed.hip -------------------------------------------------
 int deployed_pack(mdc_model* m);
+// Q6.12 integer path of the deployed nets: deployed_q612.hip
+int deployed_q612_pack(mdc_model* m);
+int deployed_q612_forward(const mdc_model* m, const void* x, int x_is_q, int64_t n, int32_t* dense, int32_t* labels, hipStream_t s);
+// eval_ops.hip
+int confusion_launch(const int32_t* truth, const int32_t* pred, int64_t n, int classes, int64_t* counts, int64_t* bad, hipStream_t s);
+int iq_u8_launch(const uint8_t* iq, int64_t n, float scale, float* x, hipStream_t s);
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
                      float* tap, int tap_kind, hipStream_t s);
 

@@ -1,0 +1,33 @@
+"""Raw SDR samples -> frames (the RTL-SDR/HPS glue of the reference's README.md:5).
+
+An RTL-SDR delivers unsigned 8-bit interleaved (I, Q) samples; a frame of the classifier is 128 such pairs
+(256 bytes).  `frames_from_iq_u8` turns a device-resident byte buffer into the (n,2,128) float32 tensor every
+`predict` entry point takes, on the device (mdc_iq_u8_to_frames), so the host never touches the samples.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _cabi
+
+DEFAULT_SCALE = 1.0 / 127.5
+
+
+def frames_from_iq_u8(iq, scale: float = DEFAULT_SCALE, device=None):
+    """iq: uint8 tensor/array with 256*n bytes (I0,Q0,I1,Q1,...).  Returns float32 (n,2,128) on the device:
+    row 0 = (I - 127.5)*scale, row 1 = (Q - 127.5)*scale.  A trailing partial frame is an error."""
+    import torch
+    t = iq if isinstance(iq, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(iq, dtype=np.uint8)))
+    if t.dtype != torch.uint8:
+        raise TypeError(f"iq must be uint8, got {t.dtype}")
+    if not t.is_cuda:
+        t = t.to(device if device is not None else "cuda:0")
+    t = t.contiguous().view(-1)
+    if t.numel() % 256:
+        raise ValueError(f"{t.numel()} bytes is not a whole number of 256-byte frames")
+    n = t.numel() // 256
+    x = torch.empty((n, 2, 128), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        _cabi.check(_cabi.lib().mdc_iq_u8_to_frames(t.data_ptr() if n else None, n, float(scale), x.data_ptr() if n else None,
+                                                    torch.cuda.current_stream(t.device).cuda_stream))
+    return x

@@ -280,14 +280,31 @@ class VTCNN2:
         return labels.cpu().numpy() if as_numpy else labels
 
     # ------------------------------------------------------------------ evaluation (cnn.py:198-216)
+    def confusion_counts_device(self, X, labels_true, batch_size: Optional[int] = None):
+        """Un-normalised C x C counts ``conf[true, predicted]`` (cnn.py:205-216) as an int64 CUDA tensor, computed
+        on the device (mdc_confusion); labels outside [0,C) raise."""
+        torch = _torch()
+        pred = self.predict_classes(X if isinstance(X, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(np.asarray(X), dtype=np.float32)).to(f"cuda:{self.device_index}"), batch_size)
+        dev = pred.device
+        truth = torch.as_tensor(np.asarray(labels_true) if not isinstance(labels_true, torch.Tensor) else labels_true)
+        truth = truth.to(device=dev, dtype=torch.int32).contiguous()
+        if truth.shape != pred.shape:
+            raise ValueError(f"labels_true has shape {tuple(truth.shape)}, predictions {tuple(pred.shape)}")
+        Cn = self.topology.classes
+        counts = torch.zeros((Cn, Cn), dtype=torch.int64, device=dev)
+        bad = torch.zeros((1,), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _cabi.check(_cabi.lib().mdc_confusion(truth.data_ptr(), pred.data_ptr(), pred.numel(), Cn, counts.data_ptr(),
+                                                  bad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        if int(bad.item()):
+            raise ValueError(f"{int(bad.item())} labels lie outside [0, {Cn})")
+        return counts
+
     def confusion(self, X, labels_true, batch_size: Optional[int] = None, normalize: bool = True) -> np.ndarray:
         """``conf[j,k] += 1`` over (true j, predicted k) then row-normalise, as cnn.py:199-216 does with the
         output of ``model.predict``; rows without samples stay 0."""
-        pred = self.predict_classes(X, batch_size)
-        pred = pred.cpu().numpy() if not isinstance(pred, np.ndarray) else pred
-        C = self.topology.classes
-        conf = np.zeros((C, C), np.float64)
-        np.add.at(conf, (np.asarray(labels_true, dtype=np.int64), pred.astype(np.int64)), 1.0)
+        conf = self.confusion_counts_device(X, labels_true, batch_size).cpu().numpy().astype(np.float64)
         if not normalize:
             return conf
         s = conf.sum(axis=1, keepdims=True)
@@ -297,6 +314,29 @@ class VTCNN2:
         """cnn.py:257-259: cor / (cor + ncor) from the un-normalised confusion counts."""
         conf = self.confusion(X, labels_true, batch_size, normalize=False)
         return float(np.trace(conf) / max(conf.sum(), 1.0))
+
+    # ------------------------------------------------------------------ FPGA arithmetic (SURVEY.md 8(f) item 1)
+    def predict_q612(self, X, as_float: bool = True):
+        """The deployed net evaluated in the FPGA's Q6.12 integer arithmetic (mdc_forward_q612; rules of
+        cnn_test_latest1.sv:642-675, 293-343).  X: float frames (n,2,128), quantised like the reference's table
+        writer (`float2fix`: trunc(v*4096)), or an integer array/tensor of Q6.12 words.  Returns (dense, labels):
+        the post-ReLU class sums as float (int/4096) or int32, and the first-max labels (int32)."""
+        torch = _torch()
+        if self.topology.kind != "deployed":
+            raise ValueError("the Q6.12 datapath exists for the deployed nets only")
+        as_numpy = not isinstance(X, torch.Tensor)
+        t = torch.as_tensor(np.asarray(X)) if as_numpy else X
+        if tuple(t.shape[1:]) != (2, 128):
+            raise ValueError(f"expected input of shape (n,2,128); got {tuple(t.shape)}")
+        is_q = not t.dtype.is_floating_point
+        t = t.to(device=f"cuda:{self.device_index}", dtype=torch.int32 if is_q else torch.float32).contiguous()
+        n, Cn = t.shape[0], self.topology.classes
+        dense = torch.empty((n, Cn), dtype=torch.int32, device=t.device)
+        labels = torch.empty((n,), dtype=torch.int32, device=t.device)
+        _cabi.check(_cabi.lib().mdc_forward_q612(self._engine(), t.data_ptr() if n else None, int(is_q), n, dense.data_ptr(),
+                                                 labels.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream))
+        out = dense.to(torch.float32) / 4096.0 if as_float else dense
+        return (out.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (out, labels)
 
     # ------------------------------------------------------------------ measurement hooks
     def set_profiling(self, on: bool) -> None:
