@@ -109,14 +109,18 @@ def dominant_roofline(m, x, probs, labels, steps):
 
 
 def cpu_baseline(name, budget_s=20.0):
-    """Numpy oracle on the host cores, bounded sample of the same workload (same seeds)."""
+    """The CPU restatement on the host cores, bounded sample of the same workload (same seeds).  Two ports are
+    timed -- torch-CPU library ops (oracle_torch) and plain numpy (oracle_np) -- and the faster one is reported;
+    neither is Keras (which cannot be installed here): kind = "port"."""
+    import torch
     from modulationdetectioncnn_amd import synthetic_frames
     from oracle import oracle_np as O        # checker / baseline only
+    from oracle import oracle_torch as OT
     kind, filters, classes, dtype, n, _ = WORKLOADS[name]
     from modulationdetectioncnn_amd import VTCNN2, Topology
     if kind == "vtcnn2":
         w = VTCNN2.synthetic(Topology.vtcnn2(classes), seed=2016).get_weights()
-        sample = 512
+        sample = 2048
     elif kind == "cnnpy":
         w = VTCNN2.synthetic(Topology.cnnpy(filters, 10, classes), seed=2016).get_weights()
         sample = 65536
@@ -125,23 +129,40 @@ def cpu_baseline(name, budget_s=20.0):
         f = "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"
         w = VTCNN2.from_npz(os.path.join(g, f)).get_weights()
         sample = 65536
-    x = synthetic_frames(sample, seed=2016)
-    O.forward(kind, x[: max(1, sample // 8)], w, dtype=np.float32)        # warm-up
-    t0 = time.perf_counter()
-    done = 0
-    while True:
-        O.forward(kind, x, w, dtype=np.float32)
-        done += sample
-        el = time.perf_counter() - t0
-        if el > budget_s * 0.5 or done >= 16 * sample:
-            break
-    try:
-        import threadpoolctl
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": done / el, "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"{done} frames ({done // sample} x {sample}) of {name}, numpy f32 oracle (CPU restatement, not Keras), {el:.1f} s"}
+    x = np.asarray(synthetic_frames(sample, seed=2016))
+    torch.set_num_threads(os.cpu_count() or 1)
+
+    def timed(fn, budget):
+        fn(x[: max(1, sample // 8)])        # warm-up
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            fn(x)
+            done += sample
+            el = time.perf_counter() - t0
+            if el > budget or done >= 32 * sample:
+                return done, el
+
+    ports = {"torch-CPU ops": (lambda a: OT.forward(kind, a, w), torch.get_num_threads()),
+             "numpy": (lambda a: O.forward(kind, a, w, dtype=np.float32), None)}
+    best = None
+    for label, (fn, threads) in ports.items():
+        done, el = timed(fn, budget_s * 0.4)
+        if threads is None:
+            try:
+                import threadpoolctl
+                threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+            except Exception:
+                threads = os.cpu_count() or 1
+        cand = {"value": done / el, "unit": "frames/s", "cores": int(threads), "kind": "port",
+                "sample": f"{done} frames ({done // sample} x {sample}) of {name}, {label} f32 restatement (not Keras), {el:.1f} s"}
+        if best is None or cand["value"] > best["value"]:
+            other = best
+            best = cand
+        else:
+            other = cand
+    best["other_port"] = {"value": other["value"], "sample": other["sample"]}
+    return best
 
 
 def run_workload(name, device, steps, warmup, dist=None):

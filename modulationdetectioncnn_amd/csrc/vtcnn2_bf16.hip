@@ -32,7 +32,6 @@ namespace mdc {
 
 namespace {
 
-template <int ABL>   // 0 = product; 1/2/3 = timing-only ablations (MDC_ABLATE env, results wrong)
 __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __restrict__ x, long n,
                                                               const u32x4* __restrict__ wq,   // [4][60][64]
                                                               const u32x2* __restrict__ a1q,  // [4][4][64]
@@ -137,13 +136,8 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         // ReLU + bf16 of the conv1 tile pair (row h, channel pair cp): already a B operand
         auto pack = [&](auto sp_tag, auto h_tag, auto cp_tag) {
             constexpr int sp = decltype(sp_tag)::value, h = decltype(h_tag)::value, cp = decltype(cp_tag)::value;
-            if (ABL == 2) return;
             const f32x4 t0 = X[2 * cp][h], t1 = X[2 * cp + 1][h];
             const u32x4 pk = u32x4{pack2relu(t0[0], t0[1]), pack2relu(t0[2], t0[3]), pack2relu(t1[0], t1[1]), pack2relu(t1[2], t1[3])};
-            if (ABL == 9) {      // timing probe: do the pack VALU work but leave conv2 independent of it
-                asm volatile("" ::"v"(pk));
-                return;
-            }
             Bf[sp][h][cp] = __builtin_bit_cast(bf16x8, pk);
         };
         // conv2, one tap j of one (row, channel pair): 5 MFMAs into the accumulators of output w'-j
@@ -160,22 +154,13 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
         // waves do identical, branch-free work.
         auto part_write = [&](auto pb_tag, const f32x4 (&a)[5]) {
             constexpr int PB = decltype(pb_tag)::value;
-            if (ABL == 1) {   // keep the accumulators live, skip exchange/barrier/store
-                for (int ot = 0; ot < 5; ++ot) asm volatile("" ::"a"(a[ot]));
-                return;
-            }
             float* pw = part + PB * kPartFloats;
-            if (ABL == 10 && q != 0) {      // timing probe: only one wave writes (LDS burst contention)
-                for (int ot = 0; ot < 5; ++ot) asm volatile("" ::"a"(a[ot]));
-                return;
-            }
 #pragma unroll
             for (int ot = 0; ot < 5; ++ot) *reinterpret_cast<f32x4*>(pw + ((q * 5 + ot) * 64 + lane) * 4) = a[ot];
         };
         auto red_load = [&](auto pb_tag) {
             constexpr int PB = decltype(pb_tag)::value;
-            if (ABL == 1) return;
-            if (ABL != 6) __syncthreads();     // s_waitcnt lgkmcnt(0) + s_barrier: every wave's partial(w) is in LDS
+            __syncthreads();     // s_waitcnt lgkmcnt(0) + s_barrier: every wave's partial(w) is in LDS
             const float* pw = part + PB * kPartFloats;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -184,11 +169,6 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
             }
         };
         auto red_finish = [&](int w) {
-            if (ABL == 1) return;
-            if (ABL == 5) {      // keep the reads live, skip the finishing VALU and the stores
-                for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(rp[k]), "v"(rc[k]));
-                return;
-            }
             const f32x4 s = (rp[0] + rp[1]) + (rp[2] + rp[3]);
             u32x2 o;
             const f32x4 bq = *reinterpret_cast<const f32x4*>(bq_lds);
@@ -197,14 +177,10 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
             unsigned short* dst = fbase + (long)w * kC2;
             const float t = ((rc[0] + rc[1]) + (rc[2] + rc[3])) + *b4_lds;
             const unsigned short t16 = (unsigned short)pack2relu(t, 0.f);
-            if (ABL == 7) {      // keep the values live, skip the global stores
-                asm volatile("" ::"v"(o), "v"(t16));
-                return;
-            }
             *reinterpret_cast<u32x2*>(dst + 16 * q) = o;
             dst[64 + q] = t16;
         };
-#define MDC_SB() do { if (ABL != 3) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MDC_SB() __builtin_amdgcn_sched_barrier(0)
         // One position step v (outputs: a0 = v+2 fresh, a1 = v+1, a2 = v completes).  TAP-MAJOR order:
         //   R1  tap 2 (20 MFMAs) -> a2 is complete; finish of output v-1 rides along
         //   R2  a2 -> LDS (its registers are not written again before R4's lgkmcnt(0) of the NEXT step:
@@ -223,7 +199,6 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
             if (!LAST) conv1_load(v + 1, par_next, I0{});
             tap(PB{}, I2{}, I0{}, I0{}, a2, false); tap(PB{}, I2{}, I0{}, I1{}, a2, false);
             tap(PB{}, I2{}, I1{}, I0{}, a2, false); tap(PB{}, I2{}, I1{}, I1{}, a2, false);
-            if (ABL == 8) MDC_SB();
             // B: the completed output goes to LDS while tap 1 (20 MFMAs, writes a1 only) runs; conv1(v+1) row 0
             //    and its pack (so row 0 of X is live inside this phase only)
             part_write(PB{}, a2);
@@ -242,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
             // (VALU writes are interlocked, XDL writes are not; hipcc does not model it).  Keeping a2 alive until
             // here -- behind the barrier's s_waitcnt lgkmcnt(0) -- stops the register allocator from handing
             // a2's registers to any MFMA before the ds_writes have completed.
-            if (ABL != 1) asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4]));
+            asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4]));
             tap(PB{}, I0{}, I0{}, I0{}, a0, true);  tap(PB{}, I0{}, I0{}, I1{}, a0, false);
             tap(PB{}, I0{}, I1{}, I0{}, a0, false);
             if (!LAST) conv1(par_next, I1{});
@@ -350,19 +325,10 @@ int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, 
     if (sched) return vtcnn2_bf16_conv_sched(m, x, n, feat, s);
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-#define MDC_LAUNCH_CONV(A) do { \
-    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds)); \
-    hipLaunchKernelGGL(vt_conv_bf16_kernel<A>, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n, \
-                       static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]), \
-                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat)); } while (0)
-#ifdef MDC_ABLATIONS   // timing-only variants for tools/ablate_conv.py (build with -DMDC_ABLATIONS); results are wrong
-    static const int abl = getenv("MDC_ABLATE") ? atoi(getenv("MDC_ABLATE")) : 0;
-    switch (abl) { case 1: MDC_LAUNCH_CONV(1); break; case 2: MDC_LAUNCH_CONV(2); break; case 3: MDC_LAUNCH_CONV(3); break; case 5: MDC_LAUNCH_CONV(5); break;
-                  case 6: MDC_LAUNCH_CONV(6); break; case 7: MDC_LAUNCH_CONV(7); break; case 8: MDC_LAUNCH_CONV(8); break; case 9: MDC_LAUNCH_CONV(9); break; case 10: MDC_LAUNCH_CONV(10); break; default: MDC_LAUNCH_CONV(0); }
-#else
-    MDC_LAUNCH_CONV(0);
-#endif
-#undef MDC_LAUNCH_CONV
+    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds));
+    hipLaunchKernelGGL(vt_conv_bf16_kernel, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n,
+                       static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]),
+                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat));
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

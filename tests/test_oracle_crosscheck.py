@@ -76,3 +76,23 @@ def test_f32_oracle_close_to_f64():
     b = O.forward("vtcnn2", x, w, dtype=np.float64)
     scale = np.abs(b["logits"]).max()
     assert np.abs(a["logits"] - b["logits"]).max() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("kind", ["deployed", "vtcnn2", "cnnpy"])
+def test_torch_port_matches_numpy_oracle(kind):
+    """oracle_torch (bench.py's multithreaded CPU baseline) against oracle_np (the one pinned to the golden vectors)."""
+    from conftest import load_deployed_npz
+    from oracle import oracle_torch as OT
+    from modulationdetectioncnn_amd.topology import Topology, synthetic_frames, synthetic_weights
+    x = np.asarray(synthetic_frames(48, seed=11)) * (4.0 if kind == "deployed" else 1.0)
+    if kind == "deployed":
+        w = load_deployed_npz("convmodrecnets_CNN2_0.5")
+    else:
+        w = synthetic_weights(Topology.vtcnn2(11) if kind == "vtcnn2" else Topology.cnnpy(10, 10, 5), seed=2016)
+    a = O.forward(kind, x, w, dtype=np.float64)
+    b = OT.forward(kind, x, w)
+    assert np.abs(a["probs"] - b["probs"]).max() < 2e-6
+    srt = np.sort(a["probs"], axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert (a["labels"][decided] == b["labels"][decided]).all()
+    assert OT.forward(kind, x[:0], w)["probs"].shape[0] == 0
