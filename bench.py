@@ -108,6 +108,25 @@ def dominant_roofline(m, x, probs, labels, steps):
     return rl, kernels
 
 
+def usable_cpus():
+    """Host threads this process may really use: CPU affinity capped by the cgroup quota (a GPU box hands each job a
+    share of its cores; asking a BLAS/OpenMP pool for every core of the machine oversubscribes that share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(name, budget_s=20.0):
     """The CPU restatement on the host cores, bounded sample of the same workload (same seeds).  Two ports are
     timed -- torch-CPU library ops (oracle_torch) and plain numpy (oracle_np) -- and the faster one is reported;
@@ -130,7 +149,13 @@ def cpu_baseline(name, budget_s=20.0):
         w = VTCNN2.from_npz(os.path.join(g, f)).get_weights()
         sample = 65536
     x = np.asarray(synthetic_frames(sample, seed=2016))
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = usable_cpus()
+    torch.set_num_threads(ncpu)
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(ncpu)
+    except Exception:
+        pass
 
     def timed(fn, budget):
         fn(x[: max(1, sample // 8)])        # warm-up
@@ -149,11 +174,7 @@ def cpu_baseline(name, budget_s=20.0):
     for label, (fn, threads) in ports.items():
         done, el = timed(fn, budget_s * 0.4)
         if threads is None:
-            try:
-                import threadpoolctl
-                threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-            except Exception:
-                threads = os.cpu_count() or 1
+            threads = ncpu
         cand = {"value": done / el, "unit": "frames/s", "cores": int(threads), "kind": "port",
                 "sample": f"{done} frames ({done // sample} x {sample}) of {name}, {label} f32 restatement (not Keras), {el:.1f} s"}
         if best is None or cand["value"] > best["value"]:
