@@ -1,11 +1,11 @@
 // Canonical VT-CNN2 (T3), bf16 path: dense1 (10560 -> 256, bias + ReLU) as a tiled MFMA GEMM.
 //
-// vt_dense1_bf16_kernel -- 256x256x64-tile bf16 GEMM (M = frames, N = 256 hidden units,
-// K = 10560), LDS-DMA staging with an XOR-swizzled source (so ds_read_b128 fragments spread
-// over the banks), two LDS buffers, 8 waves (2 x 4), fused bias + ReLU epilogue.  48 % MFMA-busy;
-// SQ_WAIT_ANY is 44 % of its wave cycles.  (Tried and dropped: a ring of four 32-deep stages with a
-// counted vmcnt(8) -- 6 % slower: the waits are the per-k-step LDS fragment reads and the barrier, not HBM
-// latency; the next step for this kernel is fragment prefetch into registers / the 8-phase schedule.)
+// Two kernels, bit-identical results (same tiles, same accumulation order):
+//   vt_dense1_bf16_kernel         256x256x64 tiles, LDS-DMA staging with an XOR-swizzled source (so ds_read_b128
+//                                 fragments spread over the banks), two LDS buffers, 8 waves (2 x 4), one
+//                                 __syncthreads per K-tile.  Simple; LDS-DMA issue + fragment reads and the MFMAs do
+//                                 not overlap (tools/ablate_dense1.py).  Kept as the race screen (MDC_DENSE1_PHASED=0).
+//   vt_dense1_bf16_phased_kernel  the production kernel; see the comment above it.
 #include "vtcnn2_bf16_common.h"
 
 #include <cstdlib>
@@ -121,6 +121,175 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned shor
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// vt_dense1_bf16_phased_kernel -- the same 256x256x64 tiles and the same accumulation order (bit-identical results),
+// restructured after the "8-phase" schedule of cdna_hip_programming.md section 5:
+//   * a K-tile is staged as four 16-KiB UNITS, one per phase, in the order the MFMA quadrants need them:
+//       U0 = rows 0..63 of each wave row-half (a0), U1 = columns 0..31 of each wave column-quarter (b0),
+//       U2 = columns 32..63 (b1), U3 = rows 64..127 (a1);
+//     phase p of tile T stages unit p of tile T+1 (other LDS buffer), so three to four units are always in flight
+//     and every wait is a counted s_waitcnt vmcnt(4), never 0, behind a raw s_barrier;
+//   * phase 0 computes quadrant (a0,b0), phase 1 (a0,b1), phase 2 (a1,b1), phase 3 (a1,b0): 4 or 8 (or 12)
+//     ds_read_b128 and 16 MFMAs per phase;
+//   * the two wave rows run half a phase apart (wave row 1 passes one extra barrier first; two barriers per phase):
+//     while one does its LDS reads / LDS-DMA issue / wait, the other issues MFMAs on the same SIMDs.
+// Ordering of LDS-DMA data for a ds_read: the issuing wave's counted vmcnt, then a barrier the reader has passed
+// (plus one more barrier for the other wave row) -- reads of a unit sit in the phase AFTER the wait that retires it.
+// ------------------------------------------------------------------------------------
+constexpr int kUnitBytes = 128 * 128;      // 128 rows x 64 bf16
+
+__global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsigned short* __restrict__ feat, long n,
+                                                                    const unsigned short* __restrict__ w1t,   // [165][256][64]
+                                                                    const float* __restrict__ c1, float* __restrict__ hid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 buffers][4 units][16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 2, wc = wv & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const long row0 = (long)blockIdx.x * kBM;
+
+    // ---- staging addresses: per phase this wave moves pieces 2wv and 2wv+1 (8 unit rows x 128 B each) of the unit
+    const int srow = lane >> 3, spos = lane & 7;
+    const unsigned short* src[4][2];      // [unit][piece]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = (wv * 2 + j) * 8 + srow;                 // unit row 0..127
+        const int sw = (spos ^ (u & 7)) * 8;                   // swizzled source chunk (LDS destination is linear)
+        const int arow_lo = 128 * (u >> 6) + (u & 63);         // tile row of U0; U3 = +64
+        const int brow_lo = 64 * (u >> 5) + (u & 31);          // B row (output column) of U1; U2 = +32
+        long g0 = row0 + arow_lo, g3 = row0 + arow_lo + 64;
+        if (g0 >= n) g0 = n - 1;                               // rows past the end are computed, not stored
+        if (g3 >= n) g3 = n - 1;
+        src[0][j] = feat + g0 * (long)kFeat + sw;
+        src[3][j] = feat + g3 * (long)kFeat + sw;
+        src[1][j] = w1t + brow_lo * kBK + sw;
+        src[2][j] = w1t + (brow_lo + 32) * kBK + sw;
+    }
+    auto stage_unit = [&](int t, int unit, int b) {
+        unsigned char* dst = smem + ((size_t)b * 4 + unit) * kUnitBytes + (wv * 2) * 1024;
+        const long koff = (unit == 0 || unit == 3) ? (long)t * kBK : (long)t * (kBN * kBK);
+        glds16(src[unit][0] + koff, dst);
+        glds16(src[unit][1] + koff, dst + 1024);
+    };
+
+    // ---- fragment read offsets inside a unit (bytes): row u, 16-B chunk (ks*4 + fg) ^ (u & 7)
+    auto frag = [&](const unsigned char* unit_base, int u, int ks) {
+        return *reinterpret_cast<const bf16x8*>(unit_base + u * 128 + (((ks * 4 + fg) ^ (u & 7)) * 16));
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+
+    auto read_a = [&](bf16x8 (&a)[4][2], int unit, int b) {
+        const unsigned char* base = smem + ((size_t)b * 4 + unit) * kUnitBytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[i][ks] = frag(base, 64 * wr + 16 * i + fr, ks);
+    };
+    auto read_b = [&](bf16x8 (&bq)[2][2], int unit, int b) {
+        const unsigned char* base = smem + ((size_t)b * 4 + unit) * kUnitBytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bq[j][ks] = frag(base, 32 * wc + 16 * j + fr, ks);
+    };
+    // one C quadrant x K = 64: rows i0..i0+3, columns j0..j0+1 of the wave's 8 x 4 fragment grid (ks inner per
+    // accumulator keeps the k order of the simple kernel)
+    auto quadrant = [&](const bf16x8 (&a)[4][2], const bf16x8 (&bq)[2][2], int i0, int j0) {
+#ifndef D1_NOPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bq[j][ks], acc[i0 + i][j0 + j], 0, 0, 0);
+#ifndef D1_NOPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+#define D1_WAIT_BARRIER(N) do { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define D1_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    // ---- prologue: tile 0 complete in buffer 0; a0 of tile 0 in registers
+#pragma unroll
+    for (int u = 0; u < 4; ++u) stage_unit(0, u, 0);
+    D1_WAIT_BARRIER(0);
+    read_a(a0, 0, 0);
+#ifndef D1_NOSTAGGER
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs half a phase behind
+#endif
+
+    // Per phase: issue the LDS-DMA of one unit of tile t+1 FIRST (longest latency), then this phase's 4 or 8 fragment
+    // reads, then the counted wait for the unit the NEXT phase reads, barrier, 16 MFMAs, barrier.
+    // With U_p(t+1) issued in phase p of tile t, the six LDS-DMA instructions outstanding at each wait are the last
+    // three units issued; vmcnt(4) retires the oldest of them:
+    //   phase 0 retires U2(t) (b1, read in phase 1)      phase 1 retires U3(t) (a1, read in phase 2)
+    //   phase 2 retires U0(t+1) (a0, read in phase 3)    phase 3 retires U1(t+1) (b0, read in phase 0 of t+1)
+    for (int t = 0; t < kNT; ++t) {
+        const int b = t & 1;
+        const bool more = t + 1 < kNT;
+        // phase 0: quadrant (a0, b0)
+        if (more) stage_unit(t + 1, 0, b ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(b0, 1, b);
+        if (more) D1_WAIT_BARRIER(4); else D1_WAIT_BARRIER(2);
+        D1_LGKM();
+        quadrant(a0, b0, 0, 0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1: quadrant (a0, b1)
+        if (more) stage_unit(t + 1, 1, b ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(b1, 2, b);
+        if (more) D1_WAIT_BARRIER(4); else D1_WAIT_BARRIER(0);
+        D1_LGKM();
+        quadrant(a0, b1, 0, 2);
+        __builtin_amdgcn_s_barrier();
+        // phase 2: quadrant (a1, b1)
+        if (more) stage_unit(t + 1, 2, b ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(a1, 3, b);
+        if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier();
+        D1_LGKM();
+        quadrant(a1, b1, 4, 2);
+        __builtin_amdgcn_s_barrier();
+        // phase 3: quadrant (a1, b0); a0 of tile t+1
+        if (more) stage_unit(t + 1, 3, b ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_a(a0, 0, b ^ 1);
+        if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier();
+        quadrant(a1, b0, 4, 0);
+        D1_LGKM();
+        __builtin_amdgcn_s_barrier();
+    }
+#ifndef D1_NOSTAGGER
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // match wave row 1's extra barrier
+#endif
+#undef D1_WAIT_BARRIER
+#undef D1_LGKM
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = wc * 64 + j * 16 + fr;
+        const float bias = c1[col];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = row0 + wr * 128 + i * 16 + fg * 4 + r;
+                if (row < n) hid[row * kHid + col] = fmaxf(acc[i][j][r] + bias, 0.f);
+            }
+    }
+}
+
 }  // namespace
 
 int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s) {
@@ -133,7 +302,16 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
     static const int abl = getenv("MDC_ABLATE_D1") ? atoi(getenv("MDC_ABLATE_D1")) : 0;
     switch (abl) { case 1: MDC_LAUNCH_D1(1); break; case 2: MDC_LAUNCH_D1(2); break; case 3: MDC_LAUNCH_D1(3); break; default: MDC_LAUNCH_D1(0); }
 #else
-    MDC_LAUNCH_D1(0);
+    // default: the phased kernel; MDC_DENSE1_PHASED=0 selects the one-barrier-per-K-tile kernel (bit-identical results)
+    static const bool phased = !(getenv("MDC_DENSE1_PHASED") && atoi(getenv("MDC_DENSE1_PHASED")) == 0);
+    if (phased) {
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
+        hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
+                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
+                           static_cast<const float*>(m->d_pack[4]), hid);
+    } else {
+        MDC_LAUNCH_D1(0);
+    }
 #endif
 #undef MDC_LAUNCH_D1
     MDC_HIP(hipGetLastError());

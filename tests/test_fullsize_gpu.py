@@ -108,3 +108,16 @@ def test_nonfinite_frames_stay_isolated(kind, dtype, n, classes):
     keep[bad] = False
     assert torch.equal(pb[keep], p[keep])
     assert torch.isfinite(pb[keep]).all()
+
+
+def test_dense1_kernels_agree_bit_for_bit():
+    """The phased dense1 GEMM (counted vmcnt waits, staggered wave rows) must equal the one-barrier-per-K-tile kernel
+    bit for bit, run after run: a hole in its LDS-DMA ordering shows up as a mismatch that comes and goes.
+    tools/ab_dense1.py runs both (MDC_DENSE1_PHASED=0/1) in child processes on 2^18 frames, four times each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dense1.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert "bit-identical across kernels and repeats: True" in r.stdout

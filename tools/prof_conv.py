@@ -11,3 +11,9 @@ x = synthetic_frames(n, seed=2016, device="cuda:0")
 for _ in range(12):
     m.forward_device(x)
 torch.cuda.synchronize()
+if len(sys.argv) > 3:      # print the HIP-event kernel times too
+    m.set_profiling(True)
+    for _ in range(8):
+        m.forward_device(x)
+    torch.cuda.synchronize()
+    print({k: round(v[0] / v[1], 4) for k, v in m.read_profile().items()})
