@@ -139,6 +139,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned shor
 // ------------------------------------------------------------------------------------
 constexpr int kUnitBytes = 128 * 128;      // 128 rows x 64 bf16
 
+template <int ABL>   // 0 = product; 1 = timing-only probe: every work-group streams the same A rows (L2 hits)
 __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsigned short* __restrict__ feat, long n,
                                                                     const unsigned short* __restrict__ w1t,   // [165][256][64]
                                                                     const float* __restrict__ c1, float* __restrict__ hid) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         const int sw = (spos ^ (u & 7)) * 8;                   // swizzled source chunk (LDS destination is linear)
         const int arow_lo = 128 * (u >> 6) + (u & 63);         // tile row of U0; U3 = +64
         const int brow_lo = 64 * (u >> 5) + (u & 31);          // B row (output column) of U1; U2 = +32
-        long g0 = row0 + arow_lo, g3 = row0 + arow_lo + 64;
+        long g0 = (ABL == 1 ? 0 : row0) + arow_lo, g3 = (ABL == 1 ? 0 : row0) + arow_lo + 64;
         if (g0 >= n) g0 = n - 1;                               // rows past the end are computed, not stored
         if (g3 >= n) g3 = n - 1;
         src[0][j] = feat + g0 * (long)kFeat + sw;
@@ -300,13 +301,23 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
                        static_cast<const float*>(m->d_pack[4]), hid); } while (0)
 #ifdef MDC_ABLATIONS
     static const int abl = getenv("MDC_ABLATE_D1") ? atoi(getenv("MDC_ABLATE_D1")) : 0;
+    if (abl == 11 || abl == 10) {      // the phased kernel: 10 = product, 11 = A rows from L2
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
+        if (abl == 11) hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<1>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
+                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]), static_cast<const float*>(m->d_pack[4]), hid);
+        else hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<0>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
+                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]), static_cast<const float*>(m->d_pack[4]), hid);
+        MDC_HIP(hipGetLastError());
+        return MDC_OK;
+    }
     switch (abl) { case 1: MDC_LAUNCH_D1(1); break; case 2: MDC_LAUNCH_D1(2); break; case 3: MDC_LAUNCH_D1(3); break; default: MDC_LAUNCH_D1(0); }
 #else
     // default: the phased kernel; MDC_DENSE1_PHASED=0 selects the one-barrier-per-K-tile kernel (bit-identical results)
     static const bool phased = !(getenv("MDC_DENSE1_PHASED") && atoi(getenv("MDC_DENSE1_PHASED")) == 0);
     if (phased) {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
-        hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
+        hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<0>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
                            static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
                            static_cast<const float*>(m->d_pack[4]), hid);
     } else {
