@@ -1,6 +1,7 @@
 // Canonical VT-CNN2 (T3), bf16 path: the production conv1+conv2 kernel (see vtcnn2_bf16.hip for the algorithm
 // and the hipcc-scheduled statement of the same computation; operand layouts of THIS kernel are described here).
 #include "vtcnn2_bf16_common.h"
+#include "vtcnn2_sched_common.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -57,11 +58,6 @@ namespace {
 //     VGPR operands die at the instruction sit where only AGPR-writing MFMAs follow (T1), never in T2's tail or C1.
 // ------------------------------------------------------------------------------------
 constexpr int kNV = 24;                   // conv2 fragments kept in VGPRs; the other 36 live in AGPRs
-constexpr int kS = 140;                   // image words per lane: entries 0..67 (66, 67 zero) + 4 pad
-constexpr int kSImgWords = 64 * kS;       // [lane][kS] per buffer
-constexpr size_t kSchedLds = (size_t)2 * kSImgWords * 4 + (size_t)2 * kPartFloats * 4;      // 112,640 B
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct SchedState {
     u32x4 Wv[kNV];
@@ -106,95 +102,6 @@ __device__ __forceinline__ void sch_packop(SchedState& st) {
         asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(d));
     }
 }
-// conv1 operand words: entries (e, e+1) of the image (16-B aligned when e is even) / entries (e, e+1) at 8-B alignment
-template <int SLOT>
-__device__ __forceinline__ void sch_load_even(SchedState& st, unsigned entry_addr) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(st.L0[SLOT]) : "v"(entry_addr) : "memory");
-}
-__device__ __forceinline__ void sch_load_odd(SchedState& st, unsigned entry_addr) {
-    asm volatile("ds_read2_b64 %0, %1 offset0:0 offset1:1" : "=v"(st.L1) : "v"(entry_addr) : "memory");
-}
-// B operand dword I (0..3) of an odd position p (R = p&3; chunk c = p>>2 in slot S0, chunk c+1 in slot SN): the words
-// of entries i, i+1, i+2 (i = p>>1) shifted by one sample.  Even positions use L0[S0] (R=0) or L1 (R=2) as loaded.
-template <int R, int S0, int SN, int I>
-__device__ __forceinline__ void sch_prep(SchedState& st) {
-    if constexpr (R == 1 || R == 3) {
-        // entries i, i+1, i+2 as (A, B) word pairs: e0 = {w[0], w[1]}, e1 = {w[2], w[3]}, e2 = {w[4], w[5]}
-        const unsigned w0 = R == 1 ? st.L0[S0][0] : st.L1[0], w1 = R == 1 ? st.L0[S0][1] : st.L1[1];
-        const unsigned w2 = R == 1 ? st.L0[S0][2] : st.L1[2], w3 = R == 1 ? st.L0[S0][3] : st.L1[3];
-        const unsigned w4 = R == 1 ? st.L1[2] : st.L0[SN][2], w5 = R == 1 ? st.L1[3] : st.L0[SN][3];
-        unsigned& d = st.cb[I];
-        if constexpr (I == 0) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w2), "v"(w0));
-        else if constexpr (I == 1) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w3), "v"(w1));
-        else if constexpr (I == 2) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w4), "v"(w2));
-        else asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(d) : "v"(w5), "v"(w3));
-    }
-}
-template <int R, int S0, int CT>
-__device__ __forceinline__ void sch_conv1_mfma(SchedState& st) {
-    const u32x4 b = R == 0 ? st.L0[S0] : R == 2 ? st.L1 : u32x4{st.cb[0], st.cb[1], st.cb[2], st.cb[3]};
-    // "=&v": the result must not share registers with an operand
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(st.X[CT]) : "v"(st.A1[CT]), "v"(b));
-}
-template <int PB, int OT>
-__device__ __forceinline__ void sch_part_write(SchedState& st, const f32x4& a) {
-    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(st.wr_addr), "a"(a), "i"(PB * kPartFloats * 4 + OT * 1024) : "memory");
-}
-// read R (0..7) of the owner's share of partial(v): even = float4 of wave R/2's partial of tile q, odd = its
-// word of tile 4
-template <int PB, int R>
-__device__ __forceinline__ void sch_red_load1(SchedState& st) {
-    constexpr int K = R >> 1;
-    if constexpr ((R & 1) == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(st.rp[K]) : "v"(st.rd_addr), "i"(PB * kPartFloats * 4 + K * 5120) : "memory");
-    else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(st.rc[K]) : "v"(st.rc_addr), "i"(PB * kPartFloats * 4 + K * 5120) : "memory");
-}
-template <int PB>
-__device__ __forceinline__ void sch_red_load(SchedState& st) {
-    sch_red_load1<PB, 0>(st); sch_red_load1<PB, 1>(st); sch_red_load1<PB, 2>(st); sch_red_load1<PB, 3>(st);
-    sch_red_load1<PB, 4>(st); sch_red_load1<PB, 5>(st); sch_red_load1<PB, 6>(st); sch_red_load1<PB, 7>(st);
-}
-// wait for every LDS operation of this wave issued so far; names the values the waited reads produce so that
-// no consumer can be scheduled above it
-__device__ __forceinline__ void sch_wait_lds(SchedState& st) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(st.rp[0]), "+v"(st.rp[1]), "+v"(st.rp[2]), "+v"(st.rp[3]), "+v"(st.rc[0]), "+v"(st.rc[1]), "+v"(st.rc[2]),
-                   "+v"(st.rc[3]), "+v"(st.L0[0]), "+v"(st.L0[1]), "+v"(st.L0[2]), "+v"(st.L1)
-                 :: "memory");
-}
-// finish of one output position, one VALU instruction per call (K = 0..20): sum of the 4 partials (the bias is
-// already in wave 0's), ReLU, bf16.  Plain v_add_f32: v_pk_add_f32 costs a whole MFMA gap.
-struct FinOut { unsigned o0, o1, tt; };
-struct FinTmp { float s[4], u[4], a, b, t; };
-template <int K>
-__device__ __forceinline__ void sch_fin(SchedState& st, FinTmp& f, FinOut& out) {
-    if constexpr (K < 4) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.s[K]) : "v"(st.rp[0][K]), "v"(st.rp[1][K]));
-    else if constexpr (K < 8) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.u[K - 4]) : "v"(st.rp[2][K - 4]), "v"(st.rp[3][K - 4]));
-    else if constexpr (K < 12) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f.s[K - 8]) : "v"(f.u[K - 8]));
-    else if constexpr (K == 12) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(out.o0) : "v"(f.s[0]), "v"(f.s[1]));
-    else if constexpr (K == 13) asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(out.o0));
-    else if constexpr (K == 14) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(out.o1) : "v"(f.s[2]), "v"(f.s[3]));
-    else if constexpr (K == 15) asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(out.o1));
-    else if constexpr (K == 16) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.a) : "v"(st.rc[0]), "v"(st.rc[1]));
-    else if constexpr (K == 17) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.b) : "v"(st.rc[2]), "v"(st.rc[3]));
-    else if constexpr (K == 18) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.t) : "v"(f.a), "v"(f.b));
-    else if constexpr (K == 19) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(out.tt) : "v"(f.t));
-    else asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(out.tt));
-}
-__device__ __forceinline__ void sch_fin_all(SchedState& st, FinOut& out) {
-    FinTmp f;
-    [&]<int... K>(std::integer_sequence<int, K...>) { (sch_fin<K>(st, f, out), ...); }(std::make_integer_sequence<int, 21>{});
-}
-// The finishing lane layout is TRANSPOSED with respect to the MFMA layout: lane L finishes frame L>>2, channel
-// chunk gs = L&3, so the four lanes of a quad write 32 (and 8) contiguous bytes of one frame's row.
-// Wave q stores channels [16q+4gs, +4) (WHICH = 0) and channel 64+4q+gs (WHICH = 1) of its lane's frame (row frow)
-// at output position w.
-template <int WHICH>
-__device__ __forceinline__ void sch_store(const FinOut& fo, unsigned short* frow, int w, int q, int gs) {
-    unsigned short* dst = frow + (long)w * kC2;
-    if constexpr (WHICH == 0) *reinterpret_cast<u32x2*>(dst + 16 * q + 4 * gs) = u32x2{fo.o0, fo.o1};
-    else dst[64 + 4 * q + gs] = (unsigned short)fo.tt;
-}
-
 // One position step.  V12 = v mod 12 fixes every register choice: Bf/partial-buffer parity (v&1), the accumulator
 // roles (v%3), the role of position v+1 in its operand chunk ((v+1)&3) and the chunk slots (((v+1)>>2)%3).
 // ABL: 0 = product; timing-only probes (tools/ablate_sched.py, -DMDC_ABLATIONS; results wrong; every conv2 MFMA stays):
@@ -309,25 +216,6 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
 #undef RD
 #undef LD
 #undef HANDOFF
-}
-
-// staging of a quarter (k) of a 16-frame group into this kernel's image layout; see stage_load in the common header
-__device__ __forceinline__ void sch_stage_write(int k, float4 v, long n, long frame0, unsigned* __restrict__ im, int tid) {
-    const int idx = tid + 256 * k;
-    const int i = idx >> 6, l = idx & 63;
-    if (frame0 + i >= n) v = make_float4(0.f, 0.f, 0.f, 0.f);      // frames past the end of the batch are zeros
-    const int h = l >> 5, m = l & 31;
-    const float xs[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float a = xs[2 * e], b = xs[2 * e + 1];
-        const unsigned hi = pack2(a, b);
-        const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
-        const unsigned lo = pack2(a - ah, b - bh);
-        unsigned* d = im + (i + 16 * h) * kS + 2 * (2 * m + 1 + e);      // samples 4m+2e, +1 -> padded pair 2m+1+e
-        *reinterpret_cast<u32x2*>(d) = u32x2{hi, lo};      // lower k-half: (x_hi, x_lo)
-        d[32 * kS] = hi;                                   // upper k-half: x_hi (its second word stays (1,1))
-    }
 }
 
 template <int ABL>
