@@ -37,6 +37,7 @@ WORKLOADS = {
     # name: (topology kind, filters, classes, dtype, per-GPU frames, weights)
     "vtcnn2-c11-bf16-n2^20": ("vtcnn2", 256, 11, "bf16", 1 << 20, "synthetic seed 2016"),
     "vtcnn2-c11-bf16-n2^21": ("vtcnn2", 256, 11, "bf16", 1 << 21, "synthetic seed 2016"),     # configs[3]: 2^24 over 8 GPUs
+    "vtcnn2-c11-fp8-n2^20": ("vtcnn2", 256, 11, "fp8", 1 << 20, "synthetic seed 2016"),       # configs[4]: fp8 MFMA conv2
     "vtcnn2-c3-f32-n65536": ("vtcnn2", 256, 3, "f32", 1 << 16, "synthetic seed 2016"),
     "vtcnn2-c11-f32-n65536": ("vtcnn2", 256, 11, "f32", 1 << 16, "synthetic seed 2016"),
     "deployed3-f32-n2^20": ("deployed", 3, 3, "f32", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),
@@ -45,7 +46,7 @@ WORKLOADS = {
     "cnnpy-f32-n2^20": ("cnnpy", 10, 5, "f32", 1 << 20, "synthetic seed 2016"),                           # cnn.py literal model
 }
 DEFAULT = "vtcnn2-c11-bf16-n2^20"
-EXTRAS = ["vtcnn2-c3-f32-n65536", "deployed3-f32-n2^20", "deployed10-f32-n2^20"]
+EXTRAS = ["vtcnn2-c3-f32-n65536", "vtcnn2-c11-fp8-n2^20", "deployed3-f32-n2^20", "deployed10-f32-n2^20"]
 
 
 def make_model(name, device):
@@ -236,7 +237,7 @@ def main():
     out = {
         "metric": "I/Q frames/sec (2x128, VT-CNN2, batch=2^20)", "value": total_frames / el, "unit": "frames/s",
         "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16"}[dtype],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8"}[dtype],
         "data": "synthetic N(0,5e-3) f32 frames resident in HBM; " + weights,
         "config": {"workload": name, "topology": kind, "classes": classes, "frames_per_gpu": n,
                    "global_batch": n * ngpu, "parallelism": f"batch-shard x{ngpu} (no collective)",

@@ -52,7 +52,9 @@ enum {
                                Layers: 0 conv, 1 dense1, 2 dense2.                                 */
 };
 
-/* Arithmetic type of the matrix products (accumulation is always f32). */
+/* Arithmetic type of the matrix products (accumulation is always f32).  MDC_BF16 and MDC_FP8 exist for
+ * MDC_KIND_VTCNN2 only.  MDC_FP8: conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16); the
+ * activations are scaled for the largest |sample| given with mdc_set_fp8_input_absmax -- larger inputs overflow. */
 enum { MDC_F32 = 0, MDC_BF16 = 1, MDC_FP8 = 2 };
 
 /* Layer taps of CNN.ipynb cell 17.  tap_dev receives, per frame:
@@ -90,8 +92,12 @@ int mdc_set_weights(mdc_model* m, int layer, const float* kernel_host, size_t ke
                     const float* bias_host, size_t bias_elems);
 
 /* Pack the weights into the kernels' register/LDS/MFMA layouts and upload them.
- * After this the model is immutable.  dtype: MDC_F32 | MDC_BF16 (MDC_FP8: ENOTSUP for now). */
+ * After this the model is immutable.  dtype: MDC_F32 | MDC_BF16 | MDC_FP8. */
 int mdc_finalize(mdc_model* m, int dtype);
+
+/* MDC_FP8 only, before mdc_finalize: the largest |I/Q sample| the caller will feed (default 0.02, the scale of the
+ * reference's bundled frames).  It fixes the power-of-two scale of the fp8 activations. */
+int mdc_set_fp8_input_absmax(mdc_model* m, float absmax);
 
 /* Bytes of caller-owned device scratch mdc_forward needs for n frames (0 for deployed). */
 size_t mdc_workspace_bytes(const mdc_model* m, int64_t n);

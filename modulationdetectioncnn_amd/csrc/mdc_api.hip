@@ -153,10 +153,9 @@ int mdc_finalize(mdc_model* m, int dtype) {
     if (m->finalized) { set_error("mdc_finalize: already finalized"); return MDC_ESTATE; }
     for (int l = 0; l < m->nlayers; ++l)
         if (!m->have[l]) { set_error("mdc_finalize: layer %d has no weights", l); return MDC_ESTATE; }
-    if (dtype == MDC_FP8) { set_error("fp8 path not implemented yet"); return MDC_ENOTSUP; }
-    if (dtype != MDC_F32 && dtype != MDC_BF16) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
-    if (dtype == MDC_BF16 && m->topo.kind != MDC_KIND_VTCNN2) {
-        set_error("bf16 is implemented for the MFMA-bound vtcnn2 family only; deployed/cnnpy nets are HBM-bound f32");
+    if (dtype != MDC_F32 && dtype != MDC_BF16 && dtype != MDC_FP8) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
+    if (dtype != MDC_F32 && m->topo.kind != MDC_KIND_VTCNN2) {
+        set_error("bf16 / fp8 are implemented for the MFMA-bound vtcnn2 family only; deployed/cnnpy nets are HBM-bound f32");
         return MDC_ENOTSUP;
     }
     m->dtype = dtype;
@@ -207,6 +206,14 @@ int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n, float* probs_d
     }
     if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
     return rc;
+}
+
+int mdc_set_fp8_input_absmax(mdc_model* m, float absmax) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    if (m->finalized) { set_error("mdc_set_fp8_input_absmax: call it before mdc_finalize"); return MDC_ESTATE; }
+    if (!(absmax > 0.f) || !(absmax < 1e30f)) { set_error("mdc_set_fp8_input_absmax: need a positive finite value"); return MDC_EINVAL; }
+    m->fp8_input_absmax = absmax;
+    return MDC_OK;
 }
 
 int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64_t n, int32_t* dense_dev, int32_t* labels_dev,

@@ -58,6 +58,11 @@ struct mdc_model {
     void* d_pack[8]{};
     size_t pack_bytes[8]{};
 
+    // fp8 mode (vtcnn2): largest |sample| the caller expects (sets the activation scale) and the resulting
+    // power-of-two scale of the features, 2^fp8_feat_scale_log2 (vtcnn2_fp8_conv.hip)
+    float fp8_input_absmax = 0.02f;
+    int fp8_feat_scale_log2 = 0;
+
     bool profiling = false;
     std::vector<mdc::ProfSlot> slots;
 };
@@ -80,6 +85,9 @@ int deployed_pack(mdc_model* m);
 // Q6.12 integer path of the deployed nets: deployed_q612.hip
 int deployed_q612_pack(mdc_model* m);
 int deployed_q612_forward(const mdc_model* m, const void* x, int x_is_q, int64_t n, int32_t* dense, int32_t* labels, hipStream_t s);
+// fp8 mode of the canonical VT-CNN2: vtcnn2_fp8_conv.hip
+int vtcnn2_fp8_pack(mdc_model* m);
+int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
 // eval_ops.hip
 int confusion_launch(const int32_t* truth, const int32_t* pred, int64_t n, int classes, int64_t* counts, int64_t* bad, hipStream_t s);
 int iq_u8_launch(const uint8_t* iq, int64_t n, float scale, float* x, hipStream_t s);

@@ -234,14 +234,14 @@ __global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restr
 
 // feat[f][w][o] (f32 or bf16) -> reference layout (80,132) channels_first, f32   ('conv'/'flat' taps)
 template <typename T>
-__global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* __restrict__ out) {
+__global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* __restrict__ out, float unscale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * kFeat) return;
     const long f = i / kFeat;
     const int r = (int)(i % kFeat);
     const int o = r / kW2, w = r % kW2;
     const T v = feat[(f * kW2 + w) * kC2 + o];
-    if constexpr (sizeof(T) == 2) out[i] = __uint_as_float(((unsigned)v) << 16);
+    if constexpr (sizeof(T) == 2) out[i] = __uint_as_float(((unsigned)v) << 16) * unscale;      // unscale = 1 or a power of two: exact
     else out[i] = v;
 }
 
@@ -278,6 +278,7 @@ int vtcnn2_pack(mdc_model* m) {
         if ((rc = upload(m, 5, pk.data(), pk.size() * sizeof(float)))) return rc;
     }
     if (m->dtype == MDC_BF16) return vtcnn2_bf16_pack(m);
+    if (m->dtype == MDC_FP8) return vtcnn2_fp8_pack(m);      // overwrites slot 2 with the scaled conv2 bias
 
     // conv2 weights: [chunk][h][j][ot][r][lane] = K2[16ot + (lane&15)][16chunk + 4(lane>>4) + r][h][j]
     std::vector<float> wp((size_t)kNChunk * kWChunkFloats);
@@ -310,7 +311,7 @@ int vtcnn2_pack(mdc_model* m) {
     return upload(m, 3, w1p.data(), w1p.size() * sizeof(float));
 }
 
-static size_t feat_elem(const mdc_model* m) { return m->dtype == MDC_BF16 ? 2 : 4; }
+static size_t feat_elem(const mdc_model* m) { return m->dtype == MDC_F32 ? 4 : 2; }      // bf16 features in bf16 and fp8 modes
 
 size_t vtcnn2_workspace_bytes(const mdc_model* m, int64_t n) {
     const size_t np = ((size_t)n + 255) & ~(size_t)255;   // kernels write whole 16-frame groups / 256-row tiles
@@ -327,8 +328,8 @@ int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, 
     float* hid = reinterpret_cast<float*>(static_cast<char*>(ws) + fbytes);
     const int C = m->topo.classes;
     int rc;
-    if (m->dtype == MDC_BF16) {
-        { ProfScope ps(m, 0, s); if ((rc = vtcnn2_bf16_conv(m, x, n, feat, s))) return rc; }
+    if (m->dtype == MDC_BF16 || m->dtype == MDC_FP8) {
+        { ProfScope ps(m, 0, s); if ((rc = m->dtype == MDC_FP8 ? vtcnn2_fp8_conv(m, x, n, feat, s) : vtcnn2_bf16_conv(m, x, n, feat, s))) return rc; }
         { ProfScope ps(m, 1, s); if ((rc = vtcnn2_bf16_dense1(m, feat, n, hid, s))) return rc; }
     } else {
         {
@@ -359,10 +360,12 @@ int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, 
     }
     if (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) {
         const long total = (long)n * kFeat;
-        if (m->dtype == MDC_BF16)
-            hipLaunchKernelGGL(vt_unpermute_kernel<unsigned short>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned short*>(feat), (long)n, tap);
+        // fp8 mode keeps its features multiplied by a power of two (dense1's weights carry the inverse)
+        const float unscale = m->dtype == MDC_FP8 ? std::ldexp(1.f, -m->fp8_feat_scale_log2) : 1.f;
+        if (m->dtype != MDC_F32)
+            hipLaunchKernelGGL(vt_unpermute_kernel<unsigned short>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned short*>(feat), (long)n, tap, unscale);
         else
-            hipLaunchKernelGGL(vt_unpermute_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(feat), (long)n, tap);
+            hipLaunchKernelGGL(vt_unpermute_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(feat), (long)n, tap, unscale);
         MDC_HIP(hipGetLastError());
     } else if (tap_kind == MDC_TAP_HIDDEN) {
         MDC_HIP(hipMemcpyAsync(tap, hid, (size_t)n * kHid * sizeof(float), hipMemcpyDeviceToDevice, s));

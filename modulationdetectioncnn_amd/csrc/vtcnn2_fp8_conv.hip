@@ -1,0 +1,372 @@
+// Canonical VT-CNN2 (T3), fp8 mode (MDC_FP8): conv1+conv2 with conv2 on the block-scaled fp8 MFMA
+// (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3, scales 2^0), twice the bf16 MFMA rate; f32 accumulation; the
+// features leave as bf16 exactly as in the bf16 mode, so dense1 and the head are the bf16 mode's kernels.
+//
+// Same structure as vtcnn2_bf16_sched.hip (weight-stationary in registers, wave q = input channels [64q, 64q+64), the
+// K-quarter partials of one output position exchanged per step, asm-sequenced step, helpers of
+// vtcnn2_sched_common.h).  What changes:
+//   * one conv2 MFMA covers a whole tap of the wave's K quarter: K = 128 = 2 I/Q rows x 64 channels, so a step has
+//     15 conv2 MFMAs (3 taps x 5 output tiles) of 32.6 cycles instead of 60 of 16.3, and the weights take 120
+//     registers instead of 240;
+//   * its B operand is the two 32x32 conv1 results of the step packed to 32 fp8 per lane.  The operand map of the
+//     instruction was probed with exact integer data (tools/microbench/mfma_fp8_probe.hip): row / column on
+//     lane&15, and the k index a function of (lane>>4, byte) common to A and B -- so the weight fragment simply
+//     stores, at (lane>>4, byte), the weight of the (row h, channel) the activation operand carries there;
+//   * ReLU is v_max_f32 on the conv1 results before v_cvt_pk_fp8_f32 (48 pack VALU per step instead of 32): with
+//     17 long MFMAs per step the kernel is VALU-issue-bound rather than MFMA-bound;
+//   * SCALING (host side only): e4m3 spans 2^-9 .. 448.  conv1's taps and bias are multiplied by 2^sa and conv2's
+//     weights by 2^sw (powers of two: exact), conv2's bias by 2^(sa+sw); the features come out multiplied by
+//     2^(sa+sw) and dense1's weights are divided by it.  sa is chosen from the largest |sample| the caller expects
+//     (mdc_set_fp8_input_absmax, default 0.02 = the reference's frames); a larger input overflows
+//     e4m3 -- "fp8 (scaled inputs)" in the survey's words.
+// Parity: unpinned like every T3 result (no weights bundled); checked against the f64 oracle at 6e-2 of max|logit|.
+#include "vtcnn2_bf16_common.h"
+#include "vtcnn2_sched_common.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace mdc {
+
+namespace {
+
+using u32x8 = __attribute__((ext_vector_type(8))) unsigned;
+constexpr int kF8Frags = 15;              // [tap j][output tile ot]
+constexpr int kF8NV = 7;                  // fragments kept in VGPRs; the other 8 live in AGPRs
+
+struct Fp8State {
+    u32x8 Wv[kF8NV];
+    u32x8 Wa[kF8Frags - kF8NV];
+    f32x4 bias[5];            // scaled conv2 bias tiles: C operand of the fresh MFMAs (wave 0; zeros on waves 1-3)
+    u32x4 A1[2];              // conv1 A operands (scaled), 32 channels x 16 k-slots each
+    unsigned Bf[2][8];        // [step parity][dword]: B operand of conv2 (32 fp8), as scalars
+    unsigned one;             // E8M0 scales 2^0 for the MFMA
+    f32x16 X[2];
+    float R[2][16];           // ReLU'd conv1 results (asm cannot update a vector element in place)
+    f32x4 rp[4];
+    float rc[4];
+    u32x4 L0[3];
+    u32x4 L1;
+    unsigned cb[4];
+    unsigned wr_addr, rd_addr, rc_addr, im_addr;
+    int gs;
+};
+
+// conv2 MFMA of tap J, output tile OT (the first one of an output, J == 0, takes the bias as C)
+template <int SP, int J, int OT>
+__device__ __forceinline__ void f8_tap(Fp8State& st, f32x4 (&acc)[5]) {
+    constexpr int IDX = J * 5 + OT;
+    const u32x8 b = u32x8{st.Bf[SP][0], st.Bf[SP][1], st.Bf[SP][2], st.Bf[SP][3], st.Bf[SP][4], st.Bf[SP][5], st.Bf[SP][6], st.Bf[SP][7]};
+    if constexpr (J == 0) {
+        if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "a"(st.bias[OT]), "v"(st.one));
+        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "a"(st.bias[OT]), "v"(st.one));
+    } else {
+        if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "v"(st.one));
+        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "v"(st.one));
+    }
+}
+// pack of conv1's results into Bf[SP]: RELU<N> (N = 0..31: v_max_f32 of result register N&15 of block N>>4 into R),
+// then CVT<K> (K = 0..15: two registers -> two fp8 in one half of dword K>>1).  Byte jb = 16*ct + r of the operand
+// holds result register r of channel block ct.
+template <int N>
+__device__ __forceinline__ void f8_relu(Fp8State& st) {
+    const float x = st.X[N >> 4][N & 15];
+    asm volatile("v_max_f32 %0, %1, 0" : "=v"(st.R[N >> 4][N & 15]) : "v"(x));
+}
+template <int SP, int K>
+__device__ __forceinline__ void f8_cvt(Fp8State& st) {
+    constexpr int d = K >> 1, ct = d >> 2, r0 = 4 * (d & 3) + 2 * (K & 1);
+    const float lo = st.R[ct][r0], hi = st.R[ct][r0 + 1];
+    if constexpr ((K & 1) == 0) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(st.Bf[SP][d]) : "v"(lo), "v"(hi));
+    else asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(st.Bf[SP][d]) : "v"(lo), "v"(hi));
+}
+
+// One position step: 15 conv2 MFMAs + 2 conv1 MFMAs, every gap 32 cycles (2 VALU, or 1 VALU + 1 LDS, ride for free).
+template <int V12, bool FIRST, bool LAST>
+__device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned short* fbase, f32x4 (&acc)[3][5]) {
+    constexpr int PAR = V12 & 1, PN = 1 - PAR;
+    constexpr int R1 = (V12 + 1) & 3, S0 = ((V12 + 1) >> 2) % 3, SN = (S0 + 1) % 3;
+    constexpr bool kLoadEven = (V12 & 3) == 1 && !LAST, kLoadOdd = (V12 & 3) == 3 && !LAST;
+    constexpr int LSLOT = ((V12 >> 2) + 1) % 3;
+    f32x4 (&a2)[5] = acc[V12 % 3];
+    f32x4 (&a1)[5] = acc[(V12 + 1) % 3];
+    f32x4 (&a0)[5] = acc[(V12 + 2) % 3];
+    const unsigned load_addr = st.im_addr + ((v >> 2) * 16 + (kLoadEven ? 16 : 24));
+    FinTmp ft;
+    FinOut fo;
+#define FIN(K) do { if (!FIRST) sch_fin<K>(st, ft, fo); } while (0)
+#define PREP(I) do { if (!LAST) sch_prep<R1, S0, SN, I>(st); } while (0)
+#define C1M(CT) do { if (!LAST) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
+#define ST(W) do { if (!FIRST) sch_store<W>(fo, fbase, v - 1, q, st.gs); } while (0)
+#define WR(OT) sch_part_write<PAR, OT>(st, a2[OT])
+#define RL(N) do { if (!LAST) f8_relu<N>(st); } while (0)
+#define CV(K) do { if (!LAST) f8_cvt<PN, K>(st); } while (0)
+#define RD(R) sch_red_load1<PAR, R>(st)
+#define LD() do { if (kLoadEven) sch_load_even<LSLOT>(st, load_addr); else if (kLoadOdd) sch_load_odd(st, load_addr); } while (0)
+#define HANDOFF() do { \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
+    sch_wait_lds(st);
+    // ---- T2: tap 2 -> a2 complete; finish of output v-1, conv1 operand dwords of v+1
+    f8_tap<PAR, 2, 0>(st, a2); FIN(0); FIN(1); FIN(2); FIN(3);
+    f8_tap<PAR, 2, 1>(st, a2); FIN(4); FIN(5); FIN(6); FIN(7);
+    f8_tap<PAR, 2, 2>(st, a2); FIN(8); FIN(9); FIN(10); FIN(11);
+    f8_tap<PAR, 2, 3>(st, a2); FIN(12); FIN(13); FIN(14); FIN(15); PREP(0); PREP(1);
+    f8_tap<PAR, 2, 4>(st, a2); FIN(16); FIN(17); FIN(18); PREP(2); PREP(3);
+    // ---- C1: conv1(v+1), the only MFMAs that write VGPRs: no feature store next to them (vtcnn2_bf16_sched.hip)
+    C1M(0); FIN(19); FIN(20); WR(0);
+    C1M(1); WR(1);
+    // ---- T1: tap 1; feature stores, the rest of the ds_writes, ReLU / fp8 pack of conv1(v+1)
+    f8_tap<PAR, 1, 0>(st, a1); ST(0); WR(2); RL(0); RL(1); RL(2); RL(3);
+    f8_tap<PAR, 1, 1>(st, a1); ST(1); RL(4); RL(5); RL(6); RL(7); RL(8); RL(9);
+    f8_tap<PAR, 1, 2>(st, a1); WR(3); RL(10); RL(11); RL(12); RL(13); RL(14); RL(15); LD();
+    f8_tap<PAR, 1, 3>(st, a1); WR(4); CV(0); CV(1); CV(2); CV(3); CV(4); CV(5);
+    f8_tap<PAR, 1, 4>(st, a1); CV(6); CV(7); RL(16); RL(17); RL(18); RL(19);
+    // ---- T0: tap 0 (fresh, C = bias); hand-off, reads of partial(v), rest of the pack
+    f8_tap<PAR, 0, 0>(st, a0); RL(20); RL(21); RL(22); RL(23); RL(24); RL(25);
+    f8_tap<PAR, 0, 1>(st, a0); HANDOFF(); RL(26); RL(27); RL(28); RL(29); RL(30); RL(31); RD(0); RD(1);
+    f8_tap<PAR, 0, 2>(st, a0); CV(8); CV(9); CV(10); CV(11); RD(2); RD(3);
+    f8_tap<PAR, 0, 3>(st, a0); CV(12); CV(13); CV(14); CV(15); RD(4); RD(5);
+    f8_tap<PAR, 0, 4>(st, a0); RD(6); RD(7);
+#undef FIN
+#undef PREP
+#undef C1M
+#undef ST
+#undef WR
+#undef RL
+#undef CV
+#undef RD
+#undef LD
+#undef HANDOFF
+}
+
+__global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __restrict__ x, long n,
+                                                             const u32x8* __restrict__ wq, const u32x4* __restrict__ a1q,
+                                                             const float* __restrict__ b2, unsigned short* __restrict__ feat) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* img = reinterpret_cast<unsigned*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 15, g = lane >> 4;
+
+    Fp8State st;
+#pragma unroll
+    for (int i = 0; i < kF8Frags; ++i) {
+        const u32x8 w = wq[(q * kF8Frags + i) * 64 + lane];
+        if (i < kF8NV) { st.Wv[i] = w; asm volatile("" : "+v"(st.Wv[i])); }
+        else { st.Wa[i - kF8NV] = w; asm volatile("" : "+a"(st.Wa[i - kF8NV])); }
+    }
+    st.A1[0] = a1q[(q * 2 + 0) * 64 + lane];
+    st.A1[1] = a1q[(q * 2 + 1) * 64 + lane];
+    st.one = 0x7F7F7F7Fu;
+    asm volatile("" : "+v"(st.one));
+#pragma unroll
+    for (int ot = 0; ot < 5; ++ot) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + 16 * ot + 4 * g);
+        st.bias[ot] = q == 0 ? b : f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+a"(st.bias[ot]));
+    }
+    const unsigned part_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem + (size_t)2 * kSImgWords * 4);
+    const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto entry = [](int f, int gg) { return 16 * (f >> 2) + 4 * (f & 3) + ((gg + (f >> 2)) & 3); };      // see vtcnn2_bf16_sched.hip
+    const int fs = lane >> 2, gs = lane & 3;
+    st.gs = gs;
+    st.wr_addr = part_lds + (q * 5 * 64 + entry(nl, g)) * 16;
+    st.rd_addr = part_lds + (q * 64 + entry(fs, gs)) * 16;
+    st.rc_addr = part_lds + (4 * 64 + entry(fs, q)) * 16 + gs * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { st.rp[k] = f32x4{0.f, 0.f, 0.f, 0.f}; st.rc[k] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) st.L0[s] = u32x4{0u, 0u, 0u, 0u};
+    st.L1 = u32x4{0u, 0u, 0u, 0u};
+    st.cb[0] = st.cb[1] = st.cb[2] = st.cb[3] = 0u;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) st.Bf[0][d] = st.Bf[1][d] = 0u;
+
+    for (int i = tid; i < 2 * kSImgWords; i += 256) img[i] = ((((i / kS) & 63) >= 32) && ((i % kS) & 1)) ? 0x3F803F80u : 0u;
+    __syncthreads();
+    const long ngroups = (n + 15) >> 4;
+    long grp = blockIdx.x;
+    if (grp < ngroups)
+        for (int k = 0; k < 4; ++k) sch_stage_write(k, stage_load(k, x, n, grp * 16, tid), n, grp * 16, img, tid);
+    __syncthreads();
+
+    int buf = 0;
+    for (; grp < ngroups; grp += gridDim.x, buf ^= 1) {
+        st.im_addr = img_lds + (buf * kSImgWords + lane * kS) * 4;
+        unsigned short* fbase = feat + (grp * 16 + fs) * (long)(kW2 * kC2);
+        const long gnext = grp + gridDim.x;
+        // accumulators of outputs 0 and 1 start from the bias: an MFMA (0 x 0 + bias), never a compiler AGPR copy
+        f32x4 acc[3][5];
+        {
+            const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %1, %2" : "=&a"(acc[0][b]) : "v"(zero), "a"(st.bias[b]));
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %2" : "=&a"(acc[1][b]) : "v"(zero), "a"(st.bias[b]));
+            }
+        }
+        // prologue: entries 0..2, conv1 of position 0 packed into Bf[0]
+        sch_load_even<0>(st, st.im_addr);
+        sch_load_odd(st, st.im_addr + 8);
+        sch_wait_lds(st);
+        sch_conv1_mfma<0, 0, 0>(st); sch_conv1_mfma<0, 0, 1>(st);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(st.X[0]), "+v"(st.X[1]));
+        [&]<int... N>(std::integer_sequence<int, N...>) { (f8_relu<N>(st), ...); }(std::make_integer_sequence<int, 32>{});
+        [&]<int... K>(std::integer_sequence<int, K...>) { (f8_cvt<0, K>(st), ...); }(std::make_integer_sequence<int, 16>{});
+        asm volatile("s_nop 1");
+
+        f8_step<0, true, false>(st, 0, q, fbase, acc);
+        int v = 1;
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int it = 0; it < 10; ++it, v += 12) {     // v = 1 .. 120
+            if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, sv, n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
+            if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load(it - 5, x, n, gnext * 16, tid);
+            f8_step<1, false, false>(st, v + 0, q, fbase, acc);
+            f8_step<2, false, false>(st, v + 1, q, fbase, acc);
+            f8_step<3, false, false>(st, v + 2, q, fbase, acc);
+            f8_step<4, false, false>(st, v + 3, q, fbase, acc);
+            f8_step<5, false, false>(st, v + 4, q, fbase, acc);
+            f8_step<6, false, false>(st, v + 5, q, fbase, acc);
+            f8_step<7, false, false>(st, v + 6, q, fbase, acc);
+            f8_step<8, false, false>(st, v + 7, q, fbase, acc);
+            f8_step<9, false, false>(st, v + 8, q, fbase, acc);
+            f8_step<10, false, false>(st, v + 9, q, fbase, acc);
+            f8_step<11, false, false>(st, v + 10, q, fbase, acc);
+            f8_step<0, false, false>(st, v + 11, q, fbase, acc);
+        }
+        f8_step<1, false, false>(st, 121, q, fbase, acc);
+        f8_step<2, false, false>(st, 122, q, fbase, acc);
+        f8_step<3, false, false>(st, 123, q, fbase, acc);
+        f8_step<4, false, false>(st, 124, q, fbase, acc);
+        f8_step<5, false, false>(st, 125, q, fbase, acc);
+        f8_step<6, false, false>(st, 126, q, fbase, acc);
+        f8_step<7, false, false>(st, 127, q, fbase, acc);
+        f8_step<8, false, false>(st, 128, q, fbase, acc);
+        f8_step<9, false, true>(st, 129, q, fbase, acc);
+        // tail: finish 129, then outputs 130 and 131 (complete as they are: only zero padding beyond).
+        // step 129 (v%3 == 0) left output 130 in acc[1] and output 131 in acc[2].
+        auto finish_store = [&](int w) {
+            FinOut fo;
+            sch_wait_lds(st);
+            sch_fin_all(st, fo);
+            sch_store<0>(fo, fbase, w, q, st.gs);
+            sch_store<1>(fo, fbase, w, q, st.gs);
+        };
+        finish_store(129);
+        asm volatile("s_nop 7\n\ts_nop 7");       // last tap-1/tap-0 MFMAs -> ds_write of their accumulators
+        sch_part_write<0, 0>(st, acc[1][0]); sch_part_write<0, 1>(st, acc[1][1]); sch_part_write<0, 2>(st, acc[1][2]);
+        sch_part_write<0, 3>(st, acc[1][3]); sch_part_write<0, 4>(st, acc[1][4]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        sch_red_load<0>(st);
+        asm volatile("" ::"a"(acc[1][0]), "a"(acc[1][1]), "a"(acc[1][2]), "a"(acc[1][3]), "a"(acc[1][4]));
+        finish_store(130);
+        sch_part_write<1, 0>(st, acc[2][0]); sch_part_write<1, 1>(st, acc[2][1]); sch_part_write<1, 2>(st, acc[2][2]);
+        sch_part_write<1, 3>(st, acc[2][3]); sch_part_write<1, 4>(st, acc[2][4]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        sch_red_load<1>(st);
+        asm volatile("" ::"a"(acc[2][0]), "a"(acc[2][1]), "a"(acc[2][2]), "a"(acc[2][3]), "a"(acc[2][4]));
+        finish_store(131);
+        __syncthreads();      // next group's image is complete; partial buffers are free again
+    }
+}
+
+}  // namespace
+
+// e4m3 (OCP "fn": no infinities, max 448, NaN = 0x7F) with round-to-nearest-even; saturates
+static unsigned char f2e4m3(float f) {
+    if (std::isnan(f)) return 0x7F;
+    const unsigned char sign = std::signbit(f) ? 0x80 : 0x00;
+    float a = std::fabs(f);
+    if (a >= 448.f) return sign | 0x7E;
+    if (a < std::ldexp(1.f, -10)) return sign;                       // below half the smallest subnormal (2^-9)
+    int e;
+    (void)std::frexp(a, &e);                                         // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                                                   // a = 1.xxx * 2^E
+    if (E < -6) E = -6;                                              // subnormal: fixed exponent
+    const float q = std::nearbyint(std::ldexp(a, 3 - E));            // mantissa with 3 fractional bits (RNE by default)
+    int m = (int)q;                                                  // 8..16 for normals, 0..8 for subnormals
+    if (m == 16) { m = 8; ++E; }
+    if (E > 8 || (E == 8 && m > 14)) return sign | 0x7E;
+    if (m < 8) return sign | (unsigned char)m;                       // subnormal: exponent field 0
+    return sign | (unsigned char)(((E + 7) << 3) | (m - 8));
+}
+
+// d_pack slots in fp8 mode: 0 conv2 fp8 fragments, 1 conv1 operands (scaled), 2 conv2 bias (scaled),
+// 3 dense1 weights (bf16, divided by the feature scale), 4 dense1 bias, 5 head.  Returns the feature scale exponent.
+int vtcnn2_fp8_pack(mdc_model* m) {
+    const float* k1 = m->hk[0].data();   // (256,1,1,3)
+    const float* b1 = m->hb[0].data();
+    const float* k2 = m->hk[1].data();   // (80,256,2,3)
+    int rc;
+    // scales: powers of two
+    float w2max = 0.f, c1bound = 0.f;
+    for (size_t i = 0; i < m->hk[1].size(); ++i) w2max = std::fmax(w2max, std::fabs(k2[i]));
+    for (int ch = 0; ch < kC1; ++ch) {
+        const float bound = m->fp8_input_absmax * (std::fabs(k1[ch * 3]) + std::fabs(k1[ch * 3 + 1]) + std::fabs(k1[ch * 3 + 2])) + std::fabs(b1[ch]);
+        c1bound = std::fmax(c1bound, bound);
+    }
+    if (!(w2max > 0.f) || !(c1bound > 0.f)) { set_error("fp8: degenerate weights (all zero)"); return MDC_EINVAL; }
+    const int sw = (int)std::floor(std::log2(224.f / w2max));      // a factor 2 of head-room below 448
+    const int sa = (int)std::floor(std::log2(224.f / c1bound));
+    const float fsw = std::ldexp(1.f, sw), fsa = std::ldexp(1.f, sa);
+    m->fp8_feat_scale_log2 = sa + sw;
+
+    std::vector<unsigned char> wq((size_t)4 * kF8Frags * 64 * 32);
+    for (int q = 0; q < 4; ++q)
+        for (int j = 0; j < 3; ++j)
+            for (int ot = 0; ot < 5; ++ot)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jb = 0; jb < 32; ++jb) {
+                        const int o = 16 * ot + (lane & 15), kg = lane >> 4, h = kg & 1, ct = jb >> 4, r = jb & 15;
+                        const int ch = 64 * q + 32 * ct + 8 * (r >> 2) + 4 * (kg >> 1) + (r & 3);
+                        wq[((((size_t)q * kF8Frags + j * 5 + ot) * 64) + lane) * 32 + jb] = f2e4m3(k2[(((size_t)o * kC1 + ch) * 2 + h) * 3 + j] * fsw);
+                    }
+    if ((rc = upload(m, 0, wq.data(), wq.size()))) return rc;
+    std::vector<unsigned short> a1((size_t)4 * 2 * 64 * 8, 0);      // as vtcnn2_bf16_pack_sched, taps and bias x 2^sa
+    for (int q = 0; q < 4; ++q)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = 64 * q + 32 * ct + (lane & 31), khalf = lane >> 5;
+                unsigned short* d = &a1[(((size_t)q * 2 + ct) * 64 + lane) * 8];
+                unsigned short th[3], tl[3];
+                for (int t = 0; t < 3; ++t) {
+                    th[t] = f2bf(k1[ch * 3 + t] * fsa);
+                    tl[t] = f2bf(k1[ch * 3 + t] * fsa - bf2f(th[t]));
+                }
+                if (khalf == 0) {
+                    d[0] = th[0]; d[1] = th[1]; d[2] = th[0]; d[3] = th[1]; d[4] = th[2]; d[6] = th[2];
+                } else {
+                    const unsigned short bh = f2bf(b1[ch] * fsa);
+                    d[0] = tl[0]; d[1] = tl[1]; d[2] = bh; d[3] = f2bf(b1[ch] * fsa - bf2f(bh)); d[4] = tl[2];
+                }
+            }
+    if ((rc = upload(m, 1, a1.data(), a1.size() * 2))) return rc;
+    std::vector<float> b2s(kC2);
+    for (int o = 0; o < kC2; ++o) b2s[o] = m->hb[1][o] * fsa * fsw;
+    if ((rc = upload(m, 2, b2s.data(), b2s.size() * sizeof(float)))) return rc;
+    // dense1: as the bf16 mode's, divided by the feature scale (exact: a power of two)
+    const float* w1 = m->hk[2].data();
+    const float inv = std::ldexp(1.f, -(sa + sw));
+    std::vector<unsigned short> w1t((size_t)kHid * kFeat);
+    for (int w = 0; w < kW2; ++w)
+        for (int o = 0; o < kC2; ++o) {
+            const float* srcw = w1 + (size_t)(o * kW2 + w) * kHid;
+            const int kk = w * kC2 + o;
+            for (int nn = 0; nn < kHid; ++nn) w1t[((size_t)(kk >> 6) * kHid + nn) * 64 + (kk & 63)] = f2bf(srcw[nn] * inv);
+        }
+    return upload(m, 3, w1t.data(), w1t.size() * 2);
+}
+
+int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {
+    const long ngroups = (n + 15) / 16;
+    const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
+    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
+    hipLaunchKernelGGL(vt_conv_fp8_kernel, dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
+                       static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]),
+                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat));
+    MDC_HIP(hipGetLastError());
+    return MDC_OK;
+}
+
+}  // namespace mdc

@@ -43,9 +43,13 @@ def _torch():
 class VTCNN2:
     """A VT-CNN2-family classifier bound to one MI355X."""
 
-    def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32"):
+    def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
+                 fp8_input_absmax: Optional[float] = None):
+        """dtype "f32" | "bf16" | "fp8" (the last two: vtcnn2 only).  fp8_input_absmax: the largest |I/Q sample| the
+        fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs overflow e4m3."""
         self.topology = topology
         self.dtype = dtype
+        self.fp8_input_absmax = fp8_input_absmax
         if dtype not in _DTYPE:
             raise ValueError(f"dtype must be one of {sorted(_DTYPE)}")
         self._device = device
@@ -173,6 +177,8 @@ class VTCNN2:
             for i, (k, b) in enumerate(self._weights):
                 _cabi.check(L.mdc_set_weights(h, i, k.ctypes.data_as(C.POINTER(C.c_float)), k.size,
                                               b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
+            if self.fp8_input_absmax is not None:
+                _cabi.check(L.mdc_set_fp8_input_absmax(h, float(self.fp8_input_absmax)))
             _cabi.check(L.mdc_finalize(h, _DTYPE[self.dtype]))
         except Exception:
             L.mdc_destroy(h)

@@ -21,7 +21,7 @@ from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("vtcnn2", "bf16", 1 << 20, 11), ("vtcnn2", "f32", 1 << 16, 3), ("deployed3", "f32", 1 << 20, 3),
+CASES = [("vtcnn2", "bf16", 1 << 20, 11), ("vtcnn2", "fp8", 1 << 18, 11), ("vtcnn2", "f32", 1 << 16, 3), ("deployed3", "f32", 1 << 20, 3),
          ("deployed10", "f32", 1 << 20, 3), ("cnnpy", "f32", 1 << 20, 5)]
 
 
@@ -72,12 +72,13 @@ def test_fullsize_properties(kind, dtype, n, classes):
     xs = x[sub].cpu().numpy()
     okind = "deployed" if kind.startswith("deployed") else kind
     ref = O.forward(okind, xs, w, dtype=np.float64)
-    tol = {"f32": 2e-5, "bf16": 2e-2}[dtype]
+    tol = {"f32": 2e-5, "bf16": 2e-2, "fp8": 8e-2}[dtype]
     got = p[sub].cpu().numpy()
     assert np.abs(got - ref["probs"]).max() <= max(2e-6, 2 * tol * np.abs(ref.get("logits", ref.get("dense"))).max())
 
 
-@pytest.mark.parametrize("kind,dtype,n,classes", [c for c in CASES if c[0] in ("vtcnn2", "cnnpy")])
+# (not fp8: its activations are scaled for a stated input range, so it is homogeneous only inside that range)
+@pytest.mark.parametrize("kind,dtype,n,classes", [c for c in CASES if c[0] in ("vtcnn2", "cnnpy") and c[1] != "fp8"])
 def test_power_of_two_scaling_is_exact(kind, dtype, n, classes):
     """Zero biases (the reference's initialisers) make the net positively homogeneous; 2^k scaling is exact."""
     m, topo, w = _model(kind, dtype, classes)

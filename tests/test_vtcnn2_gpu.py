@@ -6,6 +6,7 @@ Tolerances (relative to the largest |logit| of the batch, since the net is posit
 homogeneous in its input scale):
   f32 path : 2e-5   (exact-f32 MFMA fma chains, K up to 10560)
   bf16 path: 2e-2   (bf16 operands, f32 accumulation)
+  fp8 path : 8e-2   (conv2 on e4m3 operands, measured 3-4e-2; its activations are scaled for a stated input range)
 Labels: bit-exact wherever the oracle's top-2 logit margin exceeds 4x the tolerance."""
 import numpy as np
 import pytest
@@ -16,7 +17,7 @@ from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32": 2e-5, "bf16": 2e-2}
+TOL = {"f32": 2e-5, "bf16": 2e-2, "fp8": 8e-2}
 _cache = {}
 
 
@@ -28,9 +29,9 @@ def _setup(classes, seed=2016, bias_scale=0.0):
     return _cache[key]
 
 
-def _model(classes, dtype, **kw):
+def _model(classes, dtype, fp8_input_absmax=None, **kw):
     topo, w = _setup(classes, **kw)
-    m = VTCNN2(topo, dtype=dtype)
+    m = VTCNN2(topo, dtype=dtype, fp8_input_absmax=fp8_input_absmax if dtype == "fp8" else None)
     m.set_weights(w)
     return m, w
 
@@ -53,7 +54,7 @@ def _check(m, w, x, dtype, batch_size=None):
     return ref, decided.mean()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
 @pytest.mark.parametrize("classes", [3, 11])
 @pytest.mark.parametrize("n", [1, 16, 17, 64, 100, 257])
 def test_parity(dtype, classes, n):
@@ -62,17 +63,17 @@ def test_parity(dtype, classes, n):
     _check(m, w, x, dtype)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
 def test_parity_with_biases_and_large_inputs(dtype):
-    m, w = _model(11, dtype, seed=5, bias_scale=0.05)
     x = synthetic_frames(96, seed=7, sigma=0.5)
+    m, w = _model(11, dtype, seed=5, bias_scale=0.05, fp8_input_absmax=float(np.abs(x).max()))
     _check(m, w, x, dtype)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
 def test_taps(dtype):
-    m, w = _model(11, dtype, seed=5, bias_scale=0.05)
     x = synthetic_frames(40, seed=3, sigma=0.1)
+    m, w = _model(11, dtype, seed=5, bias_scale=0.05, fp8_input_absmax=float(np.abs(x).max()))
     ref = O.forward("vtcnn2", x, w, dtype=np.float64, taps=True)
     tol = TOL[dtype]
     flat = m.predict(x, tap="flat")
@@ -86,7 +87,7 @@ def test_taps(dtype):
     assert np.abs(hid - ref["dense1"]).max() <= tol * np.abs(ref["dense1"]).max()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
 def test_batch_size_invariance(dtype):
     m, w = _model(11, dtype)
     x = synthetic_frames(300, seed=11, device="cuda")
@@ -99,7 +100,7 @@ def test_batch_size_invariance(dtype):
 
 def test_zero_input_and_relu_exact_zero():
     # zero frames, zero biases: every activation is exactly 0 -> logits 0 -> uniform softmax, label 0
-    for dtype in ("f32", "bf16"):
+    for dtype in ("f32", "bf16", "fp8"):
         m, _ = _model(11, dtype)
         x = np.zeros((20, 2, 128), np.float32)
         p = m.predict(x)
@@ -112,3 +113,17 @@ def test_f32_larger_batch_statistics():
     x = synthetic_frames(1500, seed=99)
     _, frac = _check(m, w, x, "f32")
     assert frac > 0.999
+
+
+def test_fp8_rejects_other_topologies_and_bad_scale():
+    from conftest import load_deployed_npz
+    w = load_deployed_npz("3convmodrecnets_CNN2_0.5")
+    m = VTCNN2(Topology.deployed(3, 3), dtype="fp8")
+    m.set_weights(w)
+    with pytest.raises(Exception):
+        m.predict(np.zeros((1, 2, 128), np.float32))
+    topo, wv = _setup(3)
+    bad = VTCNN2(topo, dtype="fp8", fp8_input_absmax=-1.0)
+    bad.set_weights(wv)
+    with pytest.raises(Exception):
+        bad.predict(np.zeros((1, 2, 128), np.float32))
