@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     }
     const unsigned part_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem + (size_t)2 * kSImgWords * 4);
     const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    auto entry = [](int f, int gg) { return 16 * (f >> 2) + 4 * (f & 3) + ((gg + (f >> 2)) & 3); };      // see vtcnn2_bf16_sched.hip
+    auto entry = [](int f, int gg) { return 8 * (4 * (f >> 3) + gg) + ((f & 7) ^ (gg >> 1)); };      // see vtcnn2_bf16_sched.hip
     const int fs = lane >> 2, gs = lane & 3;
     st.gs = gs;
     st.wr_addr = part_lds + (q * 5 * 64 + entry(nl, g)) * 16;

@@ -15,6 +15,7 @@ B="python3 $R/bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt -- $B > $R/gpurun_out/pmc_fetch_vt.log 2>&1
 rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_vt -- $B > $R/gpurun_out/pmc_write_vt.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA $P -d $R/gpurun_out/pmc_mfma_vt -- $B > $R/gpurun_out/pmc_mfma_vt.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES $P -d $R/gpurun_out/pmc_lds_vt -- $B > $R/gpurun_out/pmc_lds_vt.log 2>&1
 echo "vtcnn2 counters done"
 fi
 D="python3 $R/tools/prof_deployed.py"

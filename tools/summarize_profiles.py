@@ -70,6 +70,13 @@ for key, kern in (("mdc_vt_conv/bf16", "vt_conv_bf16"), ("mdc_vt_dense1/bf16", "
     mf[key] = {"GRBM_GUI_ACTIVE_sum": c["GRBM_GUI_ACTIVE"], "cycles_per_launch": cyc, "SQ_INSTS_MFMA": c["SQ_INSTS_MFMA"],
                "SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"],
                "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cyc)}
+for key, kern in (("mdc_vt_conv/bf16", "vt_conv_bf16"), ("mdc_vt_dense1/bf16", "vt_dense1_bf16")):
+    c = counters("pmc_lds_vt", kern)
+    if c and key in mf:
+        mf[key].update({"SQ_LDS_BANK_CONFLICT": c.get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": c.get("SQ_LDS_IDX_ACTIVE"),
+                        "lds_conflict_frac": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
+                        "SQ_WAIT_ANY": c.get("SQ_WAIT_ANY"), "SQ_WAVE_CYCLES": c.get("SQ_WAVE_CYCLES"),
+                        "wave_parked_frac": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None})
 if mf:
     json.dump(mf, open(os.path.join(P, f"{rnd}_mfma.json"), "w"), indent=1)
     print(json.dumps(mf, indent=1))
