@@ -127,3 +127,19 @@ def test_fp8_rejects_other_topologies_and_bad_scale():
     bad.set_weights(wv)
     with pytest.raises(Exception):
         bad.predict(np.zeros((1, 2, 128), np.float32))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_ragged_batch_sizes_against_the_f32_kernels(dtype):
+    """Every batch size 1..48 plus the group / tile / grid boundaries (16-frame groups, 256-row GEMM tiles, 256
+    persistent work-groups): the MFMA paths against the exact-f32 path, frame by frame."""
+    mf, _ = _model(11, "f32")
+    m, _ = _model(11, dtype)
+    tol = TOL[dtype]
+    x_all = synthetic_frames(8200, seed=21, device="cuda")
+    ref_all = mf.predict(x_all, tap="dense")
+    scale = float(ref_all.abs().max())
+    for n in list(range(1, 49)) + [255, 256, 257, 511, 513, 4095, 4096, 4097, 4113, 8200]:
+        got = m.predict(x_all[:n].contiguous(), tap="dense")
+        assert got.shape == (n, 11)
+        assert float((got - ref_all[:n]).abs().max()) <= tol * scale, n
