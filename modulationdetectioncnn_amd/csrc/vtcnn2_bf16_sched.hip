@@ -51,11 +51,14 @@ namespace {
 //     (a dead destination gets reallocated and clobbered: a "no pack" timing probe faulted that way);
 //   ds_write source vs later MFMA overwrite (not interlocked for XDL writes): a2 is kept alive until after the
 //     barrier's lgkmcnt(0);
-//   compiler-made AGPR copies next to an asm MFMA are not padded (see the accumulator init in the kernel): every
+//   compiler-made AGPR copies next to an asm MFMA are not padded (see the accumulator init in the kernel; this one
+//     was PROVEN: v_accvgpr_mov directly before the asm MFMA reading it, garbage in exactly that register): every
 //     AGPR this kernel's MFMAs read is written by asm only;
-//   the same for a global_store: hipcc gave the data and address registers of a feature store, dead after it, to
-//     the conv1 MFMA that followed it (seen in the ISA; wrong features now and then).  Stores and anything else whose
-//     VGPR operands die at the instruction sit where only AGPR-writing MFMAs follow (T1), never in T2's tail or C1.
+//   precaution, not proven: hipcc once gave the data and address registers of a feature store, dead after it, to
+//     the conv1 MFMA that followed it (seen in the ISA while chasing wrong features that the AGPR-copy hazard above
+//     may equally have caused).  If a store reads its operands late, as a ds_write does, that is a wild write, so
+//     stores and anything else whose VGPR operands die at the instruction sit where only AGPR-writing MFMAs follow
+//     (T1), never in T2's tail or C1, and tools/lint_async_hazards.py checks the ISA for the pattern.
 // ------------------------------------------------------------------------------------
 constexpr int kNV = 24;                   // conv2 fragments kept in VGPRs; the other 36 live in AGPRs
 

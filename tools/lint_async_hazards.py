@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """ISA lint for a hazard hipcc does not model in the asm-sequenced conv kernel (vtcnn2_bf16_sched.hip).
 
-A memory instruction reads its VGPR operands some time AFTER it issues, and an MFMA that writes VGPRs lands its
-result long after IT issues.  When the register allocator hands the (dead) data or address registers of a
-global_store / ds_write to a following VGPR-writing MFMA, the store can go out with the MFMA's bits -- in the
-address, too.  The hardware interlocks VALU writes, not XDL writes.  Seen once in this kernel: the feature store
-of a step was followed by the first conv1 MFMA, whose destination was the store's data+address registers.
+(a) PROVEN on this kernel: hipcc implements `acc = bias` (AGPR to AGPR) with v_accvgpr_mov and may sink such a move
+right in front of an asm MFMA that reads the AGPR as its C operand; it pads that VALU-write -> MFMA-read hazard for
+its own MFMAs only, and the asm MFMA read garbage in exactly that register.
 
-A second pattern of the same family: hipcc implements `acc = bias` (AGPR to AGPR) with v_accvgpr_mov and may
-sink such a move right in front of an asm MFMA that reads the AGPR as its C operand; it pads that VALU-write ->
-MFMA-read hazard for its own MFMAs only.
+(b) PRECAUTION: a ds_write demonstrably reads its data registers some time AFTER it issues (an MFMA overwriting them
+meanwhile corrupts the stored value), and an MFMA that writes VGPRs lands its result long after IT issues.  When
+the register allocator hands the (dead) data or address registers of a global_store / ds_write to a following
+VGPR-writing MFMA, a late operand read would send the store out with the MFMA's bits -- in the address, too.  The
+pattern appeared once in this kernel's ISA (feature store followed by the first conv1 MFMA); whether a global_store
+reads late was not established, so the kernel keeps the two apart and this lint enforces it.
 
 The lint disassembles the kernel and reports every store-like instruction whose VGPR sources overlap the
 destination of a VGPR-writing MFMA issued within WINDOW instructions after it, unless an s_waitcnt that covers the
