@@ -321,6 +321,38 @@ class VTCNN2:
         conf = self.confusion(X, labels_true, batch_size, normalize=False)
         return float(np.trace(conf) / max(conf.sum(), 1.0))
 
+    def accuracy_by_snr(self, X, labels_true, snrs, batch_size: Optional[int] = None) -> Tuple[Dict, Dict]:
+        """The per-SNR loop of cnn.py:228-259: one forward over the whole batch, then for every distinct value of
+        `snrs` (one per frame) the confusion counts of that subset (device side) and acc[snr] = cor / (cor + ncor).
+        Returns (acc, conf): dicts keyed by SNR value; conf[snr] is the un-normalised C x C count matrix (numpy)."""
+        torch = _torch()
+        x = X if isinstance(X, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(np.asarray(X), dtype=np.float32)).to(f"cuda:{self.device_index}")
+        pred = self.predict_classes(x, batch_size)
+        dev = pred.device
+        truth = torch.as_tensor(np.asarray(labels_true) if not isinstance(labels_true, torch.Tensor) else labels_true)
+        truth = truth.to(device=dev, dtype=torch.int32).contiguous()
+        snr_t = torch.as_tensor(np.asarray(snrs) if not isinstance(snrs, torch.Tensor) else snrs).to(dev)
+        if truth.shape != pred.shape or snr_t.shape != pred.shape:
+            raise ValueError("labels_true and snrs need one entry per frame")
+        Cn = self.topology.classes
+        acc, conf = {}, {}
+        L = _cabi.lib()
+        for val in torch.unique(snr_t).tolist():
+            idx = (snr_t == val).nonzero().flatten()
+            t_i, p_i = truth[idx].contiguous(), pred[idx].contiguous()
+            counts = torch.zeros((Cn, Cn), dtype=torch.int64, device=dev)
+            bad = torch.zeros((1,), dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                _cabi.check(L.mdc_confusion(t_i.data_ptr(), p_i.data_ptr(), t_i.numel(), Cn, counts.data_ptr(), bad.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream))
+            if int(bad.item()):
+                raise ValueError(f"{int(bad.item())} labels lie outside [0, {Cn})")
+            c = counts.cpu().numpy()
+            conf[val] = c
+            acc[val] = float(np.trace(c)) / float(max(c.sum(), 1))
+        return acc, conf
+
     # ------------------------------------------------------------------ FPGA arithmetic (SURVEY.md 8(f) item 1)
     def predict_q612(self, X, as_float: bool = True):
         """The deployed net evaluated in the FPGA's Q6.12 integer arithmetic (mdc_forward_q612; rules of

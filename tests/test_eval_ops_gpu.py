@@ -68,3 +68,24 @@ def test_iq_u8_rejects_partial_frames():
         frames_from_iq_u8(np.zeros(300, np.uint8))
     with pytest.raises(TypeError):
         frames_from_iq_u8(torch.zeros(256, dtype=torch.int16))
+
+
+def test_accuracy_by_snr_matches_the_reference_loop():
+    """cnn.py:228-259 literally, against VTCNN2.accuracy_by_snr."""
+    m = _t1()
+    n = 5000
+    x = synthetic_frames(n, seed=4, device="cuda") * 4.0
+    rng = np.random.default_rng(2)
+    truth = rng.integers(0, 3, size=n)
+    snrs = rng.choice([-20, -10, 0, 10, 18], size=n)
+    acc, conf = m.accuracy_by_snr(x, truth, snrs)
+    pred = m.predict_classes(x).cpu().numpy()
+    for snr in sorted(set(snrs.tolist())):
+        sel = np.where(snrs == snr)[0]
+        want = np.zeros((3, 3))
+        for i in sel:                                   # cnn.py:242-245
+            want[truth[i], pred[i]] += 1
+        cor = np.sum(np.diag(want)); ncor = np.sum(want) - cor
+        np.testing.assert_array_equal(conf[snr], want.astype(np.int64))
+        assert acc[snr] == pytest.approx(1.0 * cor / (cor + ncor))
+    assert set(acc) == set(snrs.tolist())

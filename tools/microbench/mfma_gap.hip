@@ -28,6 +28,10 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     u32x4 wv = wa;
     asm volatile("" : "+a"(wa));
     asm volatile("" : "+v"(wv));
+    using u32x8 = __attribute__((ext_vector_type(8))) unsigned;
+    u32x8 w8 = u32x8{0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u}, b8 = w8;
+    unsigned one = 0x7F7F7F7Fu;
+    asm volatile("" : "+v"(w8), "+v"(b8), "+v"(one));
     f32x4 xs[8];
     using f32x16 = __attribute__((ext_vector_type(16))) float;
     f32x16 xl[2];
@@ -54,7 +58,8 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
         for (int m = 0; m < kMfmaPerIter; ++m) {
-            if (SMALL == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(xl[m % 2]) : "v"(wv), "v"(b));
+            if (SMALL == 3) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[m % 5]) : "v"(w8), "v"(b8), "v"(one));
+            else if (SMALL == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(xl[m % 2]) : "v"(wv), "v"(b));
             else if (SMALL) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xs[m % 8]) : "v"(a16), "v"(b16));
             else if (A_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m % 5]) : "a"(wa), "v"(b));
             else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m % 5]) : "v"(wv), "v"(b));
@@ -179,5 +184,12 @@ int main() {
     run<7, true, 2>("32x32x16: 4 v_add_f32 per gap", d_out, d_sink);
     run<8, true, 2>("32x32x16: 1 ds_read_b128 per gap", d_out, d_sink);
     run<21, true, 2>("32x32x16: v_add + ds_read_b128 per gap", d_out, d_sink);
+    run<0, true, 3>("f8 16x16x128: none", d_out, d_sink);
+    run<5, true, 3>("f8 16x16x128: 1 v_add_f32 per gap", d_out, d_sink);
+    run<6, true, 3>("f8 16x16x128: 2 v_add_f32 per gap", d_out, d_sink);
+    run<7, true, 3>("f8 16x16x128: 4 v_add_f32 per gap", d_out, d_sink);
+    run<8, true, 3>("f8 16x16x128: 1 ds_read_b128 per gap", d_out, d_sink);
+    run<21, true, 3>("f8 16x16x128: v_add + ds_read_b128 per gap", d_out, d_sink);
+    run<4, true, 3>("f8 16x16x128: cvt_pk + pk_max per gap", d_out, d_sink);
     return 0;
 }
