@@ -54,7 +54,7 @@ enum {
 
 /* Arithmetic type of the matrix products (accumulation is always f32).  MDC_BF16 and MDC_FP8 exist for
  * MDC_KIND_VTCNN2 only.  MDC_FP8: conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16); the
- * activations are scaled for the largest |sample| given with mdc_set_fp8_input_absmax -- larger inputs overflow. */
+ * activations are scaled for the largest |sample| given with mdc_set_fp8_input_absmax -- beyond it they saturate. */
 enum { MDC_F32 = 0, MDC_BF16 = 1, MDC_FP8 = 2 };
 
 /* Layer taps of CNN.ipynb cell 17.  tap_dev receives, per frame:

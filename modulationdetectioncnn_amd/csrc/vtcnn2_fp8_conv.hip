@@ -12,7 +12,8 @@
 //     instruction was probed with exact integer data (tools/microbench/mfma_fp8_probe.hip): row / column on
 //     lane&15, and the k index a function of (lane>>4, byte) common to A and B -- so the weight fragment simply
 //     stores, at (lane>>4, byte), the weight of the (row h, channel) the activation operand carries there;
-//   * ReLU is v_max_f32 on the conv1 results before v_cvt_pk_fp8_f32 (48 pack VALU per step instead of 32): with
+//   * ReLU is v_med3_f32(x, 0, 448) on the conv1 results (it also saturates at the e4m3 maximum, so an input beyond
+//     the stated range clips instead of turning into NaN) before v_cvt_pk_fp8_f32 (48 pack VALU per step instead of 32): with
 //     17 long MFMAs per step the kernel is VALU-issue-bound rather than MFMA-bound;
 //   * SCALING (host side only): e4m3 spans 2^-9 .. 448.  conv1's taps and bias are multiplied by 2^sa and conv2's
 //     weights by 2^sw (powers of two: exact), conv2's bias by 2^(sa+sw); the features come out multiplied by
@@ -41,6 +42,7 @@ struct Fp8State {
     u32x4 A1[2];              // conv1 A operands (scaled), 32 channels x 16 k-slots each
     unsigned Bf[2][8];        // [step parity][dword]: B operand of conv2 (32 fp8), as scalars
     unsigned one;             // E8M0 scales 2^0 for the MFMA
+    float sat;                // 448 = largest e4m3 value
     f32x16 X[2];
     float R[2][16];           // ReLU'd conv1 results (asm cannot update a vector element in place)
     f32x4 rp[4];
@@ -71,7 +73,8 @@ __device__ __forceinline__ void f8_tap(Fp8State& st, f32x4 (&acc)[5]) {
 template <int N>
 __device__ __forceinline__ void f8_relu(Fp8State& st) {
     const float x = st.X[N >> 4][N & 15];
-    asm volatile("v_max_f32 %0, %1, 0" : "=v"(st.R[N >> 4][N & 15]) : "v"(x));
+    // ReLU and saturation at the e4m3 maximum in one VALU: median(x, 0, 448)
+    asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(st.R[N >> 4][N & 15]) : "v"(x), "v"(st.sat));
 }
 template <int SP, int K>
 __device__ __forceinline__ void f8_cvt(Fp8State& st) {
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     st.A1[0] = a1q[(q * 2 + 0) * 64 + lane];
     st.A1[1] = a1q[(q * 2 + 1) * 64 + lane];
     st.one = 0x7F7F7F7Fu;
-    asm volatile("" : "+v"(st.one));
+    st.sat = 448.f;
+    asm volatile("" : "+v"(st.one), "+v"(st.sat));
 #pragma unroll
     for (int ot = 0; ot < 5; ++ot) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + 16 * ot + 4 * g);

@@ -143,3 +143,11 @@ def test_ragged_batch_sizes_against_the_f32_kernels(dtype):
         got = m.predict(x_all[:n].contiguous(), tap="dense")
         assert got.shape == (n, 11)
         assert float((got - ref_all[:n]).abs().max()) <= tol * scale, n
+
+
+def test_fp8_saturates_instead_of_nan_beyond_the_stated_range():
+    m, _ = _model(11, "fp8")                       # scaled for |x| <= 0.02
+    x = synthetic_frames(32, seed=3, sigma=0.5)      # 25x larger
+    p = m.predict(x)
+    assert np.isfinite(p).all()
+    np.testing.assert_allclose(p.sum(axis=1), 1.0, atol=1e-5)
