@@ -21,6 +21,16 @@ def test_sched_kernel_has_no_store_vs_mfma_hazard():
     assert lint.lint(isa) == []
 
 
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_fp8_kernel_has_no_store_vs_mfma_hazard():
+    spec = importlib.util.spec_from_file_location("lint_async_hazards", os.path.join(ROOT, "tools", "lint_async_hazards.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_fp8_conv.hip"), "vt_conv_fp8_kernel")
+    assert sum(1 for x in isa if x.startswith("v_mfma_scale")) > 300
+    assert lint.lint(isa) == []
+
+
 def test_lint_flags_the_pattern():
     spec = importlib.util.spec_from_file_location("lint_async_hazards", os.path.join(ROOT, "tools", "lint_async_hazards.py"))
     lint = importlib.util.module_from_spec(spec)
