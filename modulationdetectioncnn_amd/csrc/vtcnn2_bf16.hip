@@ -1,9 +1,10 @@
 // Canonical VT-CNN2 (T3), bf16 MFMA path (f32 accumulation).  See vtcnn2.hip for the math and
 // the "lane = frame" mapping.
 //
-// vt_conv_bf16_kernel / vt_conv_bf16_sched_kernel -- WEIGHT-STATIONARY IN REGISTERS.  (The second is the
-// production kernel: same algorithm, instruction order written by hand; the first is scheduled by hipcc.)  The conv2 kernel tensor is
-// 80 x 1536 bf16 = 240 KiB: too big for the 160 KiB LDS, but a CU's four SIMDs hold 512 KiB
+// vt_conv_bf16_kernel -- WEIGHT-STATIONARY IN REGISTERS.  (This is the hipcc-scheduled statement of the algorithm,
+// selectable with MDC_CONV_SCHED=0; the production kernel, vtcnn2_bf16_sched.hip, keeps the algorithm but writes the
+// instruction order by hand, runs conv1 on the 32x32 MFMA shape and uses its own image and operand order.)  The conv2
+// kernel tensor is 80 x 1536 bf16 = 240 KiB: too big for the 160 KiB LDS, but a CU's four SIMDs hold 512 KiB
 // of registers.  One workgroup = 4 waves (one per SIMD, 512 VGPR+AGPR each); wave q keeps the
 // conv2 weights of input channels [64q, 64q+64) for all 80 outputs, 2 rows and 3 taps:
 // 60 A-fragments x 4 VGPRs = 240 registers, loaded once per kernel.  The workgroup walks
