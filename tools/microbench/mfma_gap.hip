@@ -32,6 +32,9 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     u32x8 w8 = u32x8{0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u}, b8 = w8;
     unsigned one = 0x7F7F7F7Fu;
     asm volatile("" : "+v"(w8), "+v"(b8), "+v"(one));
+    u32x8 w8a = w8, b8a = w8;
+    u32x4 ba = b;
+    asm volatile("" : "+a"(w8a), "+a"(b8a), "+a"(ba));
     f32x4 xs[8];
     using f32x16 = __attribute__((ext_vector_type(16))) float;
     f32x16 xl[2];
@@ -58,7 +61,9 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
         for (int m = 0; m < kMfmaPerIter; ++m) {
-            if (SMALL == 3) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[m % 5]) : "v"(w8), "v"(b8), "v"(one));
+            if (SMALL == 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m % 5]) : "a"(wa), "a"(ba));
+            else if (SMALL == 5) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[m % 5]) : "a"(w8a), "a"(b8a), "v"(one));
+            else if (SMALL == 3) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[m % 5]) : "v"(w8), "v"(b8), "v"(one));
             else if (SMALL == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(xl[m % 2]) : "v"(wv), "v"(b));
             else if (SMALL) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=&v"(xs[m % 8]) : "v"(a16), "v"(b16));
             else if (A_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m % 5]) : "a"(wa), "v"(b));
@@ -78,6 +83,20 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
             if (F == 13 && m == 0) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(gp), "v"(p0) : "memory");
                                      asm volatile("global_store_short %0, %1, off offset:128" ::"v"(gp), "v"(c1) : "memory"); }
             if (F == 14) asm volatile("s_nop 0");
+            if (F >= 40 && F < 50) {      // N one-VGPR-source VALU: v_mov (40+N) ; v_med3 with inline constants (45+N)
+                constexpr int N = F >= 45 ? F - 45 : F - 40;
+                if (F < 45) { if (N > 0) asm volatile("v_mov_b32 %0, %1" : "=v"(c0) : "v"(c1)); if (N > 1) asm volatile("v_mov_b32 %0, %1" : "=v"(s2) : "v"(s0));
+                              if (N > 2) asm volatile("v_mov_b32 %0, %1" : "=v"(s3) : "v"(s1)); if (N > 3) asm volatile("v_mov_b32 %0, %1" : "=v"(s4) : "v"(s0)); }
+                else { if (N > 0) asm volatile("v_med3_f32 %0, %1, 0, 4.0" : "=v"(s2) : "v"(s0)); if (N > 1) asm volatile("v_med3_f32 %0, %1, 0, 4.0" : "=v"(s3) : "v"(s1));
+                       if (N > 2) asm volatile("v_med3_f32 %0, %1, 0, 4.0" : "=v"(s4) : "v"(s0)); if (N > 3) asm volatile("v_med3_f32 %0, %1, 0, 4.0" : "=v"(s5) : "v"(s1)); }
+            }
+            if (F >= 50 && F < 55) {      // N three-VGPR-source VALU (v_fma_f32)
+                constexpr int N = F - 50;
+                if (N > 0) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s2) : "v"(s0), "v"(s1), "v"(r1));
+                if (N > 1) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s3) : "v"(s0), "v"(s1), "v"(r1));
+                if (N > 2) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s4) : "v"(s0), "v"(s1), "v"(r1));
+                if (N > 3) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s5) : "v"(s0), "v"(s1), "v"(r1));
+            }
             if (F == 28) { asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(lds_addr) : "memory"); asm volatile("ds_read_b32 %0, %1" : "=v"(r1) : "v"(lds_addr4) : "memory"); }
             if (F == 29 && m == 0) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(s2) : "v"(s0), "v"(s1)); asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(p0), "s"(sbase) : "memory"); }
             if (F == 30) asm volatile("ds_read_b64 %0, %1" : "=v"(p2) : "v"(lds_addr8) : "memory");
@@ -191,5 +210,28 @@ int main() {
     run<8, true, 3>("f8 16x16x128: 1 ds_read_b128 per gap", d_out, d_sink);
     run<21, true, 3>("f8 16x16x128: v_add + ds_read_b128 per gap", d_out, d_sink);
     run<4, true, 3>("f8 16x16x128: cvt_pk + pk_max per gap", d_out, d_sink);
+    // does it matter for the free VALU slots which register file the A/B operands come from?
+    run<6, false>("2 v_add_f32 per gap", d_out, d_sink);
+    run<33, false>("3 v_add_f32 per gap", d_out, d_sink);
+    run<0, true, 4>("bf16 A,B,C all AGPR: none", d_out, d_sink);
+    run<5, true, 4>("bf16 A,B,C all AGPR: 1 v_add_f32", d_out, d_sink);
+    run<6, true, 4>("bf16 A,B,C all AGPR: 2 v_add_f32", d_out, d_sink);
+    run<33, true, 4>("bf16 A,B,C all AGPR: 3 v_add_f32", d_out, d_sink);
+    run<7, true, 4>("bf16 A,B,C all AGPR: 4 v_add_f32", d_out, d_sink);
+    run<0, true, 5>("f8 A,B,C all AGPR: none", d_out, d_sink);
+    run<6, true, 5>("f8 A,B,C all AGPR: 2 v_add_f32", d_out, d_sink);
+    run<33, true, 5>("f8 A,B,C all AGPR: 3 v_add_f32", d_out, d_sink);
+    run<7, true, 5>("f8 A,B,C all AGPR: 4 v_add_f32", d_out, d_sink);
+    run<33, true, 3>("f8 16x16x128: 3 v_add_f32 per gap", d_out, d_sink);
+    run<42, true>("2 v_mov_b32 per gap", d_out, d_sink);
+    run<43, true>("3 v_mov_b32 per gap", d_out, d_sink);
+    run<44, true>("4 v_mov_b32 per gap", d_out, d_sink);
+    run<47, true>("2 v_med3 (1 vgpr src) per gap", d_out, d_sink);
+    run<48, true>("3 v_med3 (1 vgpr src) per gap", d_out, d_sink);
+    run<52, true>("2 v_fma_f32 (3 vgpr src) per gap", d_out, d_sink);
+    run<53, true>("3 v_fma_f32 (3 vgpr src) per gap", d_out, d_sink);
+    run<44, true, 3>("f8: 4 v_mov_b32 per gap", d_out, d_sink);
+    run<49, true, 3>("f8: 4 v_med3 (1 vgpr src) per gap", d_out, d_sink);
+    run<54, true, 3>("f8: 4 v_fma_f32 per gap", d_out, d_sink);
     return 0;
 }
