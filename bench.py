@@ -202,6 +202,29 @@ def run_workload(name, device, steps, warmup, dist=None):
     return m, x, probs, labels, n, el
 
 
+def run_iq_u8(filters, device, steps=5, warmup=2, n=1 << 22):
+    """Extra leg: raw RTL-SDR bytes (256 B/frame) straight into a deployed net (mdc_forward_iq_u8)
+    with the two-pass path (mdc_iq_u8_to_frames + mdc_forward) beside it.  HBM roofline on the algorithmic bytes
+    (256 in + 12 probabilities + 4 label out), from the wall time of the timed region (one launch per step)."""
+    import torch
+    from modulationdetectioncnn_amd import frames_from_iq_u8
+    from modulationdetectioncnn_amd.sharding import timed_region
+    m, _, _ = make_model("deployed3-f32-n2^20" if filters == 3 else "deployed10-f32-n2^20", device)
+    iq = torch.randint(0, 256, (n * 256,), dtype=torch.uint8, device=f"cuda:{device}")
+    scale = 0.02 / 127.5
+    el = timed_region(lambda: m.predict_iq_u8(iq, scale), steps, warmup, sync=torch.cuda.synchronize, device=iq.device)
+    probs = torch.empty((n, 3), dtype=torch.float32, device=iq.device)
+    labels = torch.empty((n,), dtype=torch.int32, device=iq.device)
+    el2 = timed_region(lambda: m.forward_device(frames_from_iq_u8(iq, scale), probs=probs, labels=labels), steps, warmup,
+                       sync=torch.cuda.synchronize, device=iq.device)
+    gbs = (256 + 16) * n * steps / el / 1e9
+    return {"workload": f"deployed{filters}-iq-u8-n2^22", "value": n * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
+            "dtype": "f32", "input": "uint8 interleaved I/Q, 256 B/frame, resident in HBM",
+            "two_pass_value": n * steps / el2,
+            "roofline": {"bound": "hbm", "kernel": "mdc_deployed_fwd (raw-IQ form)", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "from": "wall time, one launch per step"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +289,12 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:     # an extra leg never hides the headline
                     extras.append({"workload": en, "error": repr(e)})
+            for filters in (3, 10):
+                try:
+                    extras.append(run_iq_u8(filters, device))
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    extras.append({"workload": f"deployed{filters}-iq-u8-n2^22", "error": repr(e)})
             out["extra"] = extras
     if dist:
         dist.barrier()

@@ -19,6 +19,7 @@
 #include "mdc_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace mdc {
 
@@ -165,11 +166,15 @@ __device__ __forceinline__ float rows_sum(float m) {       // sum over the four 
 
 // TAIL = true: the same arithmetic (bit-identical results, so predict() does not depend on how a batch is
 // chunked) on ONE ragged block of n < 64 frames with guarded loads and stores.
-template <int F, int TAP, int ABL = 0, bool TAIL = false>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
+// U8 = true: x points at raw interleaved unsigned 8-bit (I,Q) samples (256 B per frame, mdc_forward_iq_u8); a lane
+// loads the 8 bytes that hold its four samples of BOTH rows (lanes l and l+32 read the same address) and converts
+// the row it owns with the arithmetic of iq_u8_kernel (eval_ops.hip), so the results are bit-identical to
+// mdc_iq_u8_to_frames followed by mdc_forward -- with 256 instead of 1,024 B of HBM input per frame.
+template <int F, int TAP, int ABL = 0, bool TAIL = false, bool U8 = false>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
 __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restrict__ x, long n,
                                                            const float* __restrict__ wp,
                                                            float* __restrict__ probs, int* __restrict__ labels,
-                                                           float* __restrict__ tap_dense) {
+                                                           float* __restrict__ tap_dense, float scale = 0.f) {
     const int lane = threadIdx.x & 63;
     const int lp = lane & 31;
 
@@ -213,13 +218,32 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
         // frames stream by, read once per block by the lane that finishes the frame): no extra HBM/L2 reads
         float eI = 0.f, eQ = 0.f;
         const float4* px = reinterpret_cast<const float4*>(x + base * kFrameFloats) + lane;
-        float4 cur[4], nx[4];
-        auto load = [&](int j) {
-            if (!TAIL) return px[(long)j * 64];
-            return (j < n) ? px[(long)j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint2* pb = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(x) + base * 256) + lp;
+        using Raw = typename std::conditional<U8, uint2, float4>::type;
+        Raw cur_raw[4], nx[4];
+        float4 cur[4];
+        auto load = [&](int j) -> Raw {
+            if constexpr (U8) {
+                // past the end of a ragged block: bytes whose conversion is not used (those frames are never stored)
+                if (TAIL && j >= n) return make_uint2(0u, 0u);
+                return pb[(long)j * 32];
+            } else {
+                if (!TAIL) return px[(long)j * 64];
+                return (j < n) ? px[(long)j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        const unsigned row_shift = (lane >> 5) * 8;      // row 0 = I = even bytes, row 1 = Q = odd bytes
+        auto decode = [&](const Raw& r) -> float4 {
+            if constexpr (U8) {
+                const unsigned a = r.x >> row_shift, b = r.y >> row_shift;
+                return make_float4(((float)(a & 0xFFu) - 127.5f) * scale, ((float)((a >> 16) & 0xFFu) - 127.5f) * scale,
+                                   ((float)(b & 0xFFu) - 127.5f) * scale, ((float)((b >> 16) & 0xFFu) - 127.5f) * scale);
+            } else {
+                return r;
+            }
         };
 #pragma unroll
-        for (int f = 0; f < 4; ++f) cur[f] = load(f);
+        for (int f = 0; f < 4; ++f) cur_raw[f] = load(f);
         for (int G = 0; G < 16; ++G) {
             // prefetch the next group (the last group re-reads itself: harmless, stays in bounds).  One group
             // ahead is the measured optimum; two groups ahead (12 KB per wave in flight) was 10 % slower.
@@ -227,6 +251,8 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
 #pragma unroll
             for (int f = 0; f < 4; ++f) nx[f] = load(4 * Gn + f);
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the group
+#pragma unroll
+            for (int f = 0; f < 4; ++f) cur[f] = decode(cur_raw[f]);
             float v[4][kC];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
             }
             if (myG == G) { r[0] = m[0]; r[1] = m[1]; r[2] = m[2]; }
 #pragma unroll
-            for (int f = 0; f < 4; ++f) cur[f] = nx[f];
+            for (int f = 0; f < 4; ++f) cur_raw[f] = nx[f];
         }
         // ---- position w = 0 of both rows, all 64 frames at once: y = relu(b + K1*x[h][0]) (x[h][-1] = 0)
         if (!(ABL & 1)) { eI = e_tab[myframe * 2 + 0]; eQ = e_tab[myframe * 2 + 1]; }
@@ -400,6 +426,32 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
             if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
             else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
         }
+    }
+    MDC_HIP(hipGetLastError());
+    return MDC_OK;
+}
+
+// Raw SDR bytes straight into the deployed nets: full 64-frame blocks by the fast kernel,
+// a ragged tail by its TAIL form; no frame buffer in between.
+int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s) {
+    const float* wp = static_cast<const float*>(m->d_pack[0]);
+    const int F = m->topo.filters;
+    const long nfull = (n / 64) * 64;
+    const float* xb = reinterpret_cast<const float*>(iq);
+    ProfScope ps(m, 0, s);
+    if (nfull > 0) {
+        long grid = (nfull / 64 + 3) / 4;
+        if (grid > 2048) grid = 2048;
+        if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale);
+        else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale);
+    }
+    if (nfull < n) {
+        const long nt = n - nfull;
+        const float* xt = reinterpret_cast<const float*>(iq + nfull * 256);
+        float* pt = probs ? probs + nfull * 3 : nullptr;
+        int* lt = labels ? labels + nfull : nullptr;
+        if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale);
+        else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale);
     }
     MDC_HIP(hipGetLastError());
     return MDC_OK;

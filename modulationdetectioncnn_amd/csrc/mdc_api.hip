@@ -208,6 +208,26 @@ int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n, float* probs_d
     return rc;
 }
 
+int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, float scale, float* probs_dev, int32_t* labels_dev,
+                      void* hip_stream) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    if (!m->finalized) { set_error("mdc_forward_iq_u8: model not finalized"); return MDC_ESTATE; }
+    if (m->topo.kind != MDC_KIND_DEPLOYED) {
+        set_error("mdc_forward_iq_u8: fused raw-IQ input exists for the deployed nets only; use mdc_iq_u8_to_frames + mdc_forward");
+        return MDC_ENOTSUP;
+    }
+    if (n < 0) { set_error("mdc_forward_iq_u8: negative frame count"); return MDC_EINVAL; }
+    if (n == 0) return MDC_OK;
+    if (!iq_dev) { set_error("mdc_forward_iq_u8: null input"); return MDC_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(iq_dev) & 7) != 0) { set_error("mdc_forward_iq_u8: input must be 8-byte aligned"); return MDC_EINVAL; }
+    int cur = -1;
+    MDC_HIP(hipGetDevice(&cur));
+    if (cur != m->device) MDC_HIP(hipSetDevice(m->device));
+    const int rc = deployed_forward_iq_u8(m, iq_dev, n, scale, probs_dev, labels_dev, static_cast<hipStream_t>(hip_stream));
+    if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
+    return rc;
+}
+
 int mdc_set_fp8_input_absmax(mdc_model* m, float absmax) {
     if (!m) { set_error("null model"); return MDC_EINVAL; }
     if (m->finalized) { set_error("mdc_set_fp8_input_absmax: call it before mdc_finalize"); return MDC_ESTATE; }

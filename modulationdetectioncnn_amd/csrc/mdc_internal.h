@@ -93,6 +93,7 @@ int confusion_launch(const int32_t* truth, const int32_t* pred, int64_t n, int c
 int iq_u8_launch(const uint8_t* iq, int64_t n, float scale, float* x, hipStream_t s);
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
                      float* tap, int tap_kind, hipStream_t s);
+int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s);
 
 // ---- cnn.py literal model (T4): cnnpy.hip ----------------------------------------------
 int cnnpy_pack(mdc_model* m);

@@ -376,6 +376,37 @@ class VTCNN2:
         out = dense.to(torch.float32) / 4096.0 if as_float else dense
         return (out.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (out, labels)
 
+    # ------------------------------------------------------------------ raw SDR bytes
+    def predict_iq_u8(self, iq, scale: Optional[float] = None, batch_size: int = 0):
+        """`predict` on raw RTL-SDR samples: iq holds 256*n unsigned bytes (I0,Q0,I1,Q1,...), each sample becomes
+        (byte - 127.5) * scale (default 1/127.5).  Deployed nets read the bytes in the forward kernel itself
+        (mdc_forward_iq_u8: 256 B of HBM input per frame, no frame buffer); the other topologies convert on the
+        device first (frames_from_iq_u8) -- the results are bit-identical either way.  Returns (probs, labels) as
+        device tensors for a device tensor input, numpy arrays otherwise."""
+        torch = _torch()
+        from .frontend import DEFAULT_SCALE, frames_from_iq_u8
+        scale = DEFAULT_SCALE if scale is None else float(scale)
+        as_numpy = not isinstance(iq, torch.Tensor)
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(iq, dtype=np.uint8))) if as_numpy else iq
+        if t.dtype != torch.uint8:
+            raise TypeError(f"iq must be uint8, got {t.dtype}")
+        t = t.to(f"cuda:{self.device_index}").contiguous().view(-1)
+        if t.numel() % 256:
+            raise ValueError(f"{t.numel()} bytes is not a whole number of 256-byte frames")
+        n, Cn = t.numel() // 256, self.topology.classes
+        if self.topology.kind == "deployed":
+            probs = torch.empty((n, Cn), dtype=torch.float32, device=t.device)
+            labels = torch.empty((n,), dtype=torch.int32, device=t.device)
+            with torch.cuda.device(t.device):
+                _cabi.check(_cabi.lib().mdc_forward_iq_u8(self._engine(), t.data_ptr() if n else None, n, scale, probs.data_ptr(),
+                                                          labels.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream))
+        else:
+            x = frames_from_iq_u8(t, scale)
+            probs = torch.empty((n, Cn), dtype=torch.float32, device=t.device)
+            labels = torch.empty((n,), dtype=torch.int32, device=t.device)
+            self.forward_device(x, probs, labels, batch_size=batch_size or 65536)
+        return (probs.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (probs, labels)
+
     # ------------------------------------------------------------------ measurement hooks
     def set_profiling(self, on: bool) -> None:
         _cabi.check(_cabi.lib().mdc_set_profiling(self._engine(), int(on)))

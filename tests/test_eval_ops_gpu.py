@@ -63,6 +63,74 @@ def test_iq_u8_frontend_is_bit_exact(n):
         assert p.shape == (n, 3) and torch.isfinite(p).all()
 
 
+def _iq_to_frames_np(iq, scale):
+    """The conversion of mdc_iq_u8_to_frames restated in numpy float32 (I row 0, Q row 1)."""
+    pairs = iq.reshape(-1, 128, 2).astype(np.float32)
+    sc = np.float32(scale)
+    return np.stack([(pairs[:, :, 0] - np.float32(127.5)) * sc, (pairs[:, :, 1] - np.float32(127.5)) * sc], axis=1)
+
+
+@pytest.mark.parametrize("name", ["3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"])      # T1 (F=3), T2 (F=10)
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 191, 4096, 70001])
+def test_fused_raw_iq_forward_equals_the_two_pass_path_bit_for_bit(name, n):
+    """mdc_forward_iq_u8 (bytes read by the forward kernel) == mdc_iq_u8_to_frames + mdc_forward, exactly; and both
+    agree with the f64 oracle run on the numpy restatement of the conversion."""
+    import os
+    from conftest import GOLDEN
+    from oracle import oracle_np as O
+    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"))
+    rng = np.random.default_rng(100 + n)
+    iq = rng.integers(0, 256, size=256 * n, dtype=np.uint8)
+    scale = 0.02 / 127.5                         # samples of the size of the reference's frames
+    t = torch.from_numpy(iq).cuda()
+    probs, labels = m.predict_iq_u8(t, scale)
+    assert probs.shape == (n, 3) and labels.shape == (n,) and labels.dtype == torch.int32
+    x = frames_from_iq_u8(t, scale)
+    p2, l2, _ = m.forward_device(x)
+    assert torch.equal(probs, p2) and torch.equal(labels, l2)
+    if 0 < n <= 4096:
+        w = [a for p in load_deployed_npz(name) for a in p]
+        ref = O.forward_deployed(_iq_to_frames_np(iq, scale), *w, dtype=np.float64)
+        np.testing.assert_allclose(probs.cpu().numpy(), ref["probs"], atol=2e-6)
+    # numpy in -> numpy out
+    if n == 65:
+        pn, ln = m.predict_iq_u8(iq, scale)
+        assert isinstance(pn, np.ndarray) and np.array_equal(pn, probs.cpu().numpy()) and np.array_equal(ln, labels.cpu().numpy())
+
+
+def test_fused_raw_iq_extreme_bytes_and_default_scale():
+    """All-0, all-255 and alternating bytes (the sample range ends) through the fused kernel, default scale 1/127.5."""
+    m = _t1()
+    iq = np.concatenate([np.zeros(256 * 64, np.uint8), np.full(256 * 64, 255, np.uint8),
+                         np.tile(np.array([0, 255], np.uint8), 128 * 64), np.tile(np.array([255, 0], np.uint8), 128 * 3)])
+    probs, labels = m.predict_iq_u8(torch.from_numpy(iq).cuda())
+    x = frames_from_iq_u8(iq)
+    p2, l2, _ = m.forward_device(x)
+    assert torch.isfinite(probs).all() and torch.equal(probs, p2) and torch.equal(labels, l2)
+    assert float(x.min()) == -1.0 and float(x.max()) == 1.0
+
+
+def test_raw_iq_other_topologies_and_rejects():
+    """VT-CNN2 takes raw bytes through the device-side conversion (same call); the fused C entry refuses it."""
+    from modulationdetectioncnn_amd import _cabi
+    iq = np.random.default_rng(5).integers(0, 256, size=256 * 40, dtype=np.uint8)
+    m = VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, device=0, dtype="f32")
+    probs, labels = m.predict_iq_u8(iq, 0.02 / 127.5)
+    want = m.predict(frames_from_iq_u8(iq, 0.02 / 127.5))
+    np.testing.assert_array_equal(probs, want.cpu().numpy())
+    t = torch.from_numpy(iq).cuda()
+    out = torch.empty((40, 11), dtype=torch.float32, device="cuda")
+    rc = _cabi.lib().mdc_forward_iq_u8(m._engine(), t.data_ptr(), 40, 1.0, out.data_ptr(), None, None)
+    assert rc == -95 and b"deployed" in _cabi.lib().mdc_last_error()
+    d = _t1()
+    with pytest.raises(ValueError):
+        d.predict_iq_u8(np.zeros(300, np.uint8))
+    with pytest.raises(TypeError):
+        d.predict_iq_u8(torch.zeros(256, dtype=torch.int16))
+    with pytest.raises(_cabi.MdcError):          # misaligned byte pointer
+        _cabi.check(_cabi.lib().mdc_forward_iq_u8(d._engine(), t.data_ptr() + 4, 1, 1.0, None, None, None))
+
+
 def test_iq_u8_rejects_partial_frames():
     with pytest.raises(ValueError):
         frames_from_iq_u8(np.zeros(300, np.uint8))
