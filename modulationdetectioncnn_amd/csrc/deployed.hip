@@ -177,6 +177,8 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                                                            float* __restrict__ tap_dense, float scale = 0.f) {
     const int lane = threadIdx.x & 63;
     const int lp = lane & 31;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    constexpr bool kPacked = F >= 8 && !(ABL & 8);
 
     float k0[F], k1[F], cb[F], bd[kC];
 #pragma unroll
@@ -263,7 +265,25 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                 if (!(ABL & 1) && lp == 0) e_tab[(4 * G + f) * 2 + (lane >> 5)] = cur[f].x;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f;
                 if (ABL & 4) { s0 = xs[0] + xs[1]; s1 = xs[2] + xs[3]; s2 = xs[4]; }     // memory-only probe
-                else
+                else if constexpr (kPacked) {
+                    // F = 10 is VALU-bound: two positions per v_pk_fma_f32 (same issue rate as v_fma_f32,
+                    // tools/microbench/valu_rate.hip) -- 140 instead of 240 VALU per frame for the conv + dense part
+                    const f32x2 xm[2] = {f32x2{xs[0], xs[1]}, f32x2{xs[2], xs[3]}};
+                    const f32x2 xc[2] = {f32x2{xs[1], xs[2]}, f32x2{xs[3], xs[4]}};
+                    f32x2 a0 = f32x2{0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+                    for (int ff = 0; ff < F; ++ff)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            f32x2 y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff]}, xc[pr],
+                                                                __builtin_elementwise_fma(f32x2{k0[ff], k0[ff]}, xm[pr], f32x2{cb[ff], cb[ff]}));
+                            y = f32x2{fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
+                            a0 = __builtin_elementwise_fma(f32x2{wd[2 * pr][ff][0], wd[2 * pr + 1][ff][0]}, y, a0);
+                            a1 = __builtin_elementwise_fma(f32x2{wd[2 * pr][ff][1], wd[2 * pr + 1][ff][1]}, y, a1);
+                            a2 = __builtin_elementwise_fma(f32x2{wd[2 * pr][ff][2], wd[2 * pr + 1][ff][2]}, y, a2);
+                        }
+                    s0 = a0.x + a0.y; s1 = a1.x + a1.y; s2 = a2.x + a2.y;
+                } else
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
