@@ -202,7 +202,7 @@ def run_workload(name, device, steps, warmup, dist=None):
     return m, x, probs, labels, n, el
 
 
-def run_iq_u8(filters, device, steps=5, warmup=2, n=1 << 22):
+def run_iq_u8(filters, device, steps=20, warmup=5, n=1 << 22):
     """Extra leg: raw RTL-SDR bytes (256 B/frame) straight into a deployed net (mdc_forward_iq_u8)
     with the two-pass path (mdc_iq_u8_to_frames + mdc_forward) beside it.  HBM roofline on the algorithmic bytes
     (256 in + 12 probabilities + 4 label out), from the wall time of the timed region (one launch per step)."""
