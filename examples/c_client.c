@@ -1,0 +1,84 @@
+/* A caller of libmdc.so written in plain C99: no C++, no torch, no Python -- only include/mdc.h and the HIP
+ * runtime's C API for the device buffers the caller owns.  It does for a deployed net (CNN.ipynb cell 6) what the
+ * reference does with Keras (cnn.py:147 load_weights, cnn.py:198 predict, cnn.py:209 argmax):
+ *
+ *     c_client <weights.bin> <frames.bin> <n> <out.bin> [F]
+ *
+ * weights.bin: float32 conv kernel (2F, HWIO), conv bias (F), dense kernel (258F x 3), dense bias (3);
+ * frames.bin:  n x 2 x 128 float32;   out.bin: n x 3 float32 probabilities, then n int32 labels.
+ *
+ * Build (tests/test_c_client.py does exactly this):
+ *     gcc -std=c99 -Wall -Werror -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/c_client.c \
+ *         -Lmodulationdetectioncnn_amd -lmdc -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,... -o c_client
+ */
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include "mdc.h"
+
+static void* read_file(const char* path, size_t bytes) {
+    FILE* f = fopen(path, "rb");
+    void* p = malloc(bytes ? bytes : 1);
+    if (!f || !p || fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "cannot read %zu bytes from %s\n", bytes, path); exit(2); }
+    fclose(f);
+    return p;
+}
+
+#define MDC_CHECK(call) do { int rc_ = (call); if (rc_ != MDC_OK) { \
+    fprintf(stderr, "%s -> %d: %s\n", #call, rc_, mdc_last_error()); return 1; } } while (0)
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 5) { fprintf(stderr, "usage: %s weights.bin frames.bin n out.bin [F]\n", argv[0]); return 2; }
+    const long n = atol(argv[3]);
+    const int F = argc > 5 ? atoi(argv[5]) : 3;
+    const size_t nk0 = 2 * (size_t)F, nb0 = (size_t)F, nk1 = 258 * (size_t)F * 3, nb1 = 3;
+    float* w = (float*)read_file(argv[1], (nk0 + nb0 + nk1 + nb1) * sizeof(float));
+    float* x = (float*)read_file(argv[2], (size_t)n * 256 * sizeof(float));
+
+    if (mdc_abi_version() != MDC_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+    mdc_topology topo = {MDC_KIND_DEPLOYED, 0, 0, 3, {0, 0, 0, 0}};
+    topo.filters = F;
+    mdc_model* m = NULL;
+    MDC_CHECK(mdc_create(&topo, 0, &m));
+    size_t ke = 0, be = 0;
+    MDC_CHECK(mdc_layer_sizes(m, 0, &ke, &be));
+    if (mdc_num_layers(m) != 2 || ke != nk0 || be != nb0) { fprintf(stderr, "unexpected layer sizes\n"); return 1; }
+    MDC_CHECK(mdc_set_weights(m, 0, w, nk0, w + nk0, nb0));
+    MDC_CHECK(mdc_set_weights(m, 1, w + nk0 + nb0, nk1, w + nk0 + nb0 + nk1, nb1));
+    /* calling forward before finalize is an ordering error the library reports, it does not crash */
+    if (mdc_forward(m, x, n, NULL, NULL, NULL, MDC_TAP_NONE, NULL, 0, NULL) != MDC_ESTATE) { fprintf(stderr, "expected MDC_ESTATE\n"); return 1; }
+    MDC_CHECK(mdc_finalize(m, MDC_F32));
+
+    float *x_dev = NULL, *p_dev = NULL;
+    int32_t* l_dev = NULL;
+    hipStream_t s;
+    HIP_CHECK(hipSetDevice(0));
+    HIP_CHECK(hipStreamCreate(&s));
+    HIP_CHECK(hipMalloc((void**)&x_dev, (size_t)(n ? n : 1) * 256 * sizeof(float)));
+    HIP_CHECK(hipMalloc((void**)&p_dev, (size_t)(n ? n : 1) * 3 * sizeof(float)));
+    HIP_CHECK(hipMalloc((void**)&l_dev, (size_t)(n ? n : 1) * sizeof(int32_t)));
+    HIP_CHECK(hipMemcpyAsync(x_dev, x, (size_t)n * 256 * sizeof(float), hipMemcpyHostToDevice, s));
+    MDC_CHECK(mdc_forward(m, x_dev, n, p_dev, l_dev, NULL, MDC_TAP_NONE, NULL, mdc_workspace_bytes(m, n), s));
+    float* p = (float*)malloc((size_t)(n ? n : 1) * 3 * sizeof(float));
+    int32_t* l = (int32_t*)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
+    HIP_CHECK(hipMemcpyAsync(p, p_dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(l, l_dev, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+
+    FILE* out = fopen(argv[4], "wb");
+    if (!out || fwrite(p, sizeof(float), (size_t)n * 3, out) != (size_t)n * 3 || fwrite(l, sizeof(int32_t), (size_t)n, out) != (size_t)n) {
+        fprintf(stderr, "cannot write %s\n", argv[4]);
+        return 1;
+    }
+    fclose(out);
+    mdc_destroy(m);
+    HIP_CHECK(hipFree(x_dev)); HIP_CHECK(hipFree(p_dev)); HIP_CHECK(hipFree(l_dev));
+    HIP_CHECK(hipStreamDestroy(s));
+    free(w); free(x); free(p); free(l);
+    printf("c_client: %ld frames classified\n", n);
+    return 0;
+}

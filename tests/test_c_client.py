@@ -1,0 +1,62 @@
+"""include/mdc.h is a C header and libmdc.so a C library: a plain-C99 caller (examples/c_client.c) compiles against it
+with gcc -- no C++, no torch -- and, on the GPU, reproduces the oracle's probabilities for the bundled T1 net."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_deployed_npz
+
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+SRC = os.path.join(ROOT, "examples", "c_client.c")
+CFLAGS = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROCM, "include")]
+
+
+def test_header_is_plain_c99(tmp_path):
+    tu = tmp_path / "only_header.c"
+    tu.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 1 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(tu)], check=True)
+
+
+def test_c_client_compiles_and_links_without_cxx_or_torch(tmp_path):
+    import modulationdetectioncnn_amd.build as b
+    lib = b.build()
+    exe = tmp_path / "c_client"
+    subprocess.run(CFLAGS + [SRC, "-L", os.path.dirname(lib), "-lmdc", "-L", os.path.join(ROCM, "lib"), "-lamdhip64",
+                             f"-Wl,-rpath,{os.path.dirname(lib)}", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}", "-o", str(exe)], check=True)
+    # the caller itself needs neither the C++ runtime nor torch/python at link time
+    needed = subprocess.run(["readelf", "-d", str(exe)], check=True, capture_output=True, text=True).stdout
+    libs = [ln.split("[")[1].rstrip("]") for ln in needed.splitlines() if "NEEDED" in ln]
+    assert any(x.startswith("libmdc") for x in libs) and any(x.startswith("libamdhip64") for x in libs)
+    assert not any("stdc++" in x or "torch" in x or "python" in x for x in libs), libs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 1000])
+def test_c_client_reproduces_the_oracle(tmp_path, n):
+    from modulationdetectioncnn_amd import synthetic_frames
+    from oracle import oracle_np as O
+    import modulationdetectioncnn_amd.build as b
+    lib = b.build()
+    exe = tmp_path / "c_client"
+    subprocess.run(CFLAGS + [SRC, "-L", os.path.dirname(lib), "-lmdc", "-L", os.path.join(ROCM, "lib"), "-lamdhip64",
+                             f"-Wl,-rpath,{os.path.dirname(lib)}", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}", "-o", str(exe)], check=True)
+    (ck, cb), (dk, db) = load_deployed_npz("3convmodrecnets_CNN2_0.5")
+    np.concatenate([np.asarray(a, np.float32).ravel() for a in (ck, cb, dk, db)]).tofile(tmp_path / "w.bin")
+    x = np.asarray(synthetic_frames(n, seed=11), np.float32)
+    x.tofile(tmp_path / "x.bin")
+    r = subprocess.run([str(exe), str(tmp_path / "w.bin"), str(tmp_path / "x.bin"), str(n), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint8)
+    probs = raw[: n * 12].view(np.float32).reshape(n, 3)
+    labels = raw[n * 12:].view(np.int32)
+    assert labels.shape == (n,)
+    if n:
+        ref = O.forward_deployed(x, ck, cb, dk, db, dtype=np.float64)
+        np.testing.assert_allclose(probs, ref["probs"], atol=2e-6)
+        srt = np.sort(ref["dense"], axis=1)
+        decided = (srt[:, -1] - srt[:, -2]) > 1e-5 * np.maximum(np.abs(ref["dense"]).max(axis=1), 1e-30)
+        assert (labels[decided] == ref["labels"][decided]).all()
