@@ -55,7 +55,7 @@ class VTCNN2:
         self._device = device
         self._weights: Optional[Weights] = None
         self._handle: Optional[C.c_void_p] = None
-        self._ws = None
+        self._ws = {}
         self.default_chunk = 1 << 16 if topology.kind == "vtcnn2" else 1 << 22
 
     # ------------------------------------------------------------------ construction
@@ -190,7 +190,7 @@ class VTCNN2:
         if self._handle is not None:
             _cabi.lib().mdc_destroy(self._handle)
             self._handle = None
-        self._ws = None
+        self._ws = {}
 
     def __del__(self):
         try:
@@ -204,9 +204,14 @@ class VTCNN2:
         if need == 0:
             return None, 0
         torch = _torch()
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=f"cuda:{self.device_index}")
-        return self._ws, need
+        # one scratch buffer PER STREAM: forwards enqueued on different streams run concurrently and must not share
+        # it (the C ABI leaves the workspace to the caller for exactly this reason); allocated under the stream
+        # that uses it, so torch's caching allocator orders any reuse after the launches already queued there
+        key = torch.cuda.current_stream(torch.device("cuda", self.device_index)).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=f"cuda:{self.device_index}")
+        return ws, need
 
     # ------------------------------------------------------------------ inference
     def tap_shape(self, tap: str) -> Tuple[int, ...]:

@@ -151,3 +151,25 @@ def test_fp8_saturates_instead_of_nan_beyond_the_stated_range():
     p = m.predict(x)
     assert np.isfinite(p).all()
     np.testing.assert_allclose(p.sum(axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_two_streams_share_one_model(dtype):
+    """mdc_forward is re-entrant on a finalized model (include/mdc.h): forwards of one model enqueued on two HIP
+    streams at once, each with its own workspace, give exactly what they give one after the other."""
+    m = VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, device=0, dtype=dtype)
+    n = 8192 if dtype == "bf16" else 2048
+    xa = synthetic_frames(n, seed=21, device="cuda:0")
+    xb = synthetic_frames(n, seed=22, device="cuda:0")
+    pa, la, _ = m.forward_device(xa, batch_size=1024)
+    pb, lb, _ = m.forward_device(xb, batch_size=1024)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            qa, ka, _ = m.forward_device(xa, batch_size=1024)
+        with torch.cuda.stream(sb):
+            qb, kb, _ = m.forward_device(xb, batch_size=1024)
+        torch.cuda.synchronize()
+        assert torch.equal(qa, pa) and torch.equal(ka, la) and torch.equal(qb, pb) and torch.equal(kb, lb)
+    assert len(m._ws) == 3          # default stream + the two above: one scratch buffer each
