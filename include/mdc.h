@@ -52,8 +52,9 @@ enum {
                                Layers: 0 conv, 1 dense1, 2 dense2.                                 */
 };
 
-/* Arithmetic type of the matrix products (accumulation is always f32).  MDC_BF16 and MDC_FP8 exist for
- * MDC_KIND_VTCNN2 only.  MDC_FP8: conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16); the
+/* Arithmetic type of the matrix products (accumulation is always f32).  MDC_BF16: MDC_KIND_VTCNN2 (both convs'
+ * and dense1's operands) and MDC_KIND_DEPLOYED (the dense layer's operands; the conv stays f32; no layer taps).
+ * MDC_FP8: MDC_KIND_VTCNN2 only -- conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16); the
  * activations are scaled for the largest |sample| given with mdc_set_fp8_input_absmax -- beyond it they saturate. */
 enum { MDC_F32 = 0, MDC_BF16 = 1, MDC_FP8 = 2 };
 

@@ -404,6 +404,10 @@ int deployed_pack(mdc_model* m) {
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
                      float* tap, int tap_kind, hipStream_t s) {
     if (tap_kind == MDC_TAP_HIDDEN) { set_error("deployed nets have no hidden dense layer to tap"); return MDC_EINVAL; }
+    if (m->dtype == MDC_BF16) {
+        if (tap_kind != MDC_TAP_NONE) { set_error("layer taps of the deployed nets are served by the f32 kernels (finalize with MDC_F32)"); return MDC_ENOTSUP; }
+        return deployed_bf16_forward(m, x, n, probs, labels, s);
+    }
     const float* wp = static_cast<const float*>(m->d_pack[0]);
     const int F = m->topo.filters;
     float* tap_conv = (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) ? tap : nullptr;

@@ -1,0 +1,259 @@
+// Deployed single-conv nets (T1: F=3, T2: F=10) with the dense layer on the bf16 matrix cores (MDC_BF16).
+//
+// Why: the f32 kernel (deployed.hip) is one wave = one frame, each lane multiplying ITS conv outputs by ITS dense
+// weights on the vector ALU -- 3 FMAs per conv output, which for F = 10 (2,580 outputs x 3 classes per frame) makes the
+// kernel VALU-bound at a third of the HBM roofline.  Here the dense layer is a GEMM on v_mfma_f32_16x16x32_bf16:
+//     D[class][frame] += A[class][k] * B[k][frame],   k = one conv output of the frame,
+// which needs "lane = frame": the MFMA's B operand of lane (n = lane & 15, kg = lane >> 4) is 8 k-values of column
+// (frame) n.  So a wave takes 16 frames at a time and lane (f, g) owns a QUARTER of frame f: the sixteen 4-sample
+// pieces p = 4j + g (j = 0..15) of the frame's 64 pieces (row I = pieces 0..31, row Q = 32..63), read from a staging
+// area in LDS that LDS-DMA fills 1 KiB (one frame) per instruction, every byte of the batch exactly once.  For each piece the lane computes its 4 conv positions x F filters in f32 (same fma chain
+// as deployed.hip: fma(K1, x[w], fma(K0, x[w-1], b))), applies ReLU on the packed bf16 halves, and the values ARE the
+// B operand (k order = order of production; the host lays the dense weights out to match, zero rows for classes
+// 3..15).  The sample x[w] a piece lacks for its last position is the first sample of the NEXT piece: one extra
+// ds_read_b32, zero at the row end.  Position w = 0 of each row (x[-1] = 0) is an extra 2F values that
+// only the g = 0 lane of a frame owns (the other lanes' weights for those slots are zero).
+// VALU per frame: 2 v_pk_fma_f32 + cvt_pk + pk_max per two outputs = 81 instead of ~180; the dense part is 8F + 1..3
+// MFMAs per 16 frames with A (three non-zero rows) read from a table in LDS.
+// Numerics: conv in f32 exactly as the f32 kernel; conv outputs and dense weights rounded to bf16 (RNE), products
+// accumulated in f32 by the MFMA; bias, ReLU, softmax, first-max argmax in f32 as in deployed.hip.
+#include "vtcnn2_bf16_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace mdc {
+
+namespace {
+
+constexpr int kC = 3;
+
+template <int F>
+struct Bf16Geom {
+    static constexpr int kUnitPieces = (4 * F) % 8 == 0 ? 1 : 2;      // pieces whose values fill whole MFMAs
+    static constexpr int kUnitVals = kUnitPieces * 4 * F;
+    static constexpr int kUnitMfma = kUnitVals / 8;
+    static constexpr int kUnits = 16 / kUnitPieces;
+    static constexpr int kMainMfma = kUnits * kUnitMfma;              // = 8F
+    static constexpr int kExtraMfma = (2 * F + 7) / 8;                // position w = 0 of both rows
+    static constexpr int kMfma = kMainMfma + kExtraMfma;
+    static constexpr int kATabBytes = kMfma * 4 * kC * 16;            // A table, rows 0..2 only: [mfma][kg][class][8 bf16]
+    static constexpr int kFrameStride = 1024 + 16;                    // staged frame + pad (spreads the 16 frames over the banks)
+    static constexpr int kStageBytes = 16 * kFrameStride;             // one 16-frame group per wave
+    static constexpr int kWaves = 8;
+    static constexpr size_t kLds = (size_t)kATabBytes + (size_t)kWaves * kStageBytes;
+};
+
+// Frames reach the lanes through a wave-private LDS staging area filled by LDS-DMA: one global_load_lds_dwordx4 per
+// frame moves 1 KiB fully coalesced (lane l -> bytes 16l..16l+15, the access pattern of deployed.hip), and lane (f, g)
+// then reads its pieces 4j + g of frame f with ds_read_b128 (+ the next piece's first sample with a ds_read_b32).
+// Loading the pieces straight from global memory -- 64 contiguous bytes per frame per instruction -- ran at 3.5e9
+// frames/s for F = 3 and F = 10 alike: bound by that access pattern, not by arithmetic.
+template <int F>
+__global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
+                                                               const float* __restrict__ wp, const uint4* __restrict__ atab,
+                                                               float* __restrict__ probs, int* __restrict__ labels) {
+    using G = Bf16Geom<F>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* a_lds = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < G::kATabBytes / 16; i += blockDim.x) a_lds[i] = atab[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int f = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* stage = smem + G::kATabBytes + wv * G::kStageBytes;
+    const unsigned char* mine = stage + f * G::kFrameStride + g * 16;      // piece 4j + g of frame f at mine + 64 j
+    // this lane's A row: class c = lane & 15, k-group g.  Rows 3..15 of the MFMA are never read back, so their
+    // lanes simply load class 0's weights again (no zero rows in LDS, no masking)
+    const uint4* a_mine = a_lds + g * kC + (f < kC ? f : 0);
+
+    float k0[F], k1[F], cb[F], bd[kC];
+#pragma unroll
+    for (int i = 0; i < F; ++i) { k0[i] = wp[3 * i + 0]; k1[i] = wp[3 * i + 1]; cb[i] = wp[3 * i + 2]; }
+#pragma unroll
+    for (int c = 0; c < kC; ++c) bd[c] = wp[3 * F + c];
+
+    const long ngroups = (n + 15) >> 4;
+    const long gstep = (long)gridDim.x * G::kWaves;
+    auto stage_group = [&](long grp) {       // 16 x 1 KiB, frames past the end of the batch re-read the last one
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long fr = grp * 16 + i;
+            glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + lane * 4, stage + i * G::kFrameStride);
+        }
+    };
+    long grp = (long)blockIdx.x * G::kWaves + wv;
+    if (grp < ngroups) stage_group(grp);
+    for (; grp < ngroups; grp += gstep) {
+        const long frame = grp * 16 + f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed in its own staging area
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float x0[2] = {0.f, 0.f};      // first sample of piece 0 / piece 32 (rows' x[0], for the g = 0 lane)
+        // LDS reads run one unit ahead of the arithmetic: pieces, next-piece samples and the A rows of unit u + 1 are
+        // requested before unit u is computed (the sched_barrier that bounds the register use would otherwise put
+        // every unit's LDS latency in front of its own arithmetic)
+        float4 c4n[G::kUnitPieces];
+        float nbn[G::kUnitPieces];
+        uint4 an[G::kUnitMfma];
+        auto read_unit = [&](int u) {
+#pragma unroll
+            for (int q = 0; q < G::kUnitPieces; ++q) {
+                const int j = u * G::kUnitPieces + q;
+                c4n[q] = *reinterpret_cast<const float4*>(mine + 64 * j);
+                nbn[q] = *reinterpret_cast<const float*>(mine + 64 * j + 16);
+            }
+#pragma unroll
+            for (int mm = 0; mm < G::kUnitMfma; ++mm) an[mm] = a_mine[(u * G::kUnitMfma + mm) * 4 * kC];
+        };
+        read_unit(0);
+#pragma unroll
+        for (int u = 0; u < G::kUnits; ++u) {
+            float4 c4[G::kUnitPieces];
+            float nbv[G::kUnitPieces];
+            uint4 a[G::kUnitMfma];
+#pragma unroll
+            for (int q = 0; q < G::kUnitPieces; ++q) { c4[q] = c4n[q]; nbv[q] = nbn[q]; }
+#pragma unroll
+            for (int mm = 0; mm < G::kUnitMfma; ++mm) a[mm] = an[mm];
+            if (u + 1 < G::kUnits) {
+                read_unit(u + 1);
+            } else {
+#pragma unroll
+                for (int mm = 0; mm < G::kExtraMfma; ++mm) an[mm] = a_mine[(G::kMainMfma + mm) * 4 * kC];      // for the w = 0 part
+            }
+            float vals[G::kUnitVals];
+#pragma unroll
+            for (int q = 0; q < G::kUnitPieces; ++q) {
+                const int j = u * G::kUnitPieces + q;
+                // the last piece of a row (p & 31 == 31: g == 3, j == 7 or 15) has no next sample: x[128] = 0
+                if ((j == 7 || j == 15) && g == 3) nbv[q] = 0.f;
+                if (j == 0) x0[0] = c4[q].x;
+                if (j == 8) x0[1] = c4[q].x;
+                const float xs[5] = {c4[q].x, c4[q].y, c4[q].z, c4[q].w, nbv[q]};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (F % 2 == 0) {
+#pragma unroll
+                        for (int ff = 0; ff < F; ff += 2) {
+                            const f32x2 y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff + 1]}, f32x2{xs[s + 1], xs[s + 1]},
+                                                                      __builtin_elementwise_fma(f32x2{k0[ff], k0[ff + 1]}, f32x2{xs[s], xs[s]},
+                                                                                                f32x2{cb[ff], cb[ff + 1]}));
+                            vals[(q * 4 + s) * F + ff] = y.x;
+                            vals[(q * 4 + s) * F + ff + 1] = y.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int ff = 0; ff < F; ++ff) vals[(q * 4 + s) * F + ff] = fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < G::kUnitMfma; ++mm) {
+                const int m = u * G::kUnitMfma + mm;
+                const u32x4 b = u32x4{pack2relu(vals[8 * mm + 0], vals[8 * mm + 1]), pack2relu(vals[8 * mm + 2], vals[8 * mm + 3]),
+                                      pack2relu(vals[8 * mm + 4], vals[8 * mm + 5]), pack2relu(vals[8 * mm + 6], vals[8 * mm + 7])};
+                acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mm]), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep each unit's values inside the unit (register budget)
+        }
+        // every read of the staging area is done: the next group's frames can come in while the rest is computed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp + gstep < ngroups) stage_group(grp + gstep);
+        {   // position w = 0 of row I (piece 0) and row Q (piece 32), owned by the g = 0 lane: y = relu(b + K1 x[0]);
+            // lanes g != 0 compute the same expression on finite samples of their own and meet zero weights
+            float ev[8 * G::kExtraMfma];
+#pragma unroll
+            for (int i = 0; i < 8 * G::kExtraMfma; ++i) ev[i] = 0.f;
+#pragma unroll
+            for (int ff = 0; ff < F; ++ff) {
+                ev[ff] = fmaf(k1[ff], x0[0], cb[ff]);
+                ev[F + ff] = fmaf(k1[ff], x0[1], cb[ff]);
+            }
+#pragma unroll
+            for (int mm = 0; mm < G::kExtraMfma; ++mm) {
+                const int m = G::kMainMfma + mm;
+                const u32x4 b = u32x4{pack2relu(ev[8 * mm + 0], ev[8 * mm + 1]), pack2relu(ev[8 * mm + 2], ev[8 * mm + 3]),
+                                      pack2relu(ev[8 * mm + 4], ev[8 * mm + 5]), pack2relu(ev[8 * mm + 6], ev[8 * mm + 7])};
+                const uint4 a = an[mm];
+                acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+            }
+        }
+        // D rows 0..2 (the classes) of column f live in lanes 0..15 (kg = 0), registers 0..2
+        if (g == 0 && frame < n) {
+            const float z0 = fmaxf(acc[0][0] + acc[1][0] + bd[0], 0.f);      // Dense(3, activation='relu')
+            const float z1 = fmaxf(acc[0][1] + acc[1][1] + bd[1], 0.f);
+            const float z2 = fmaxf(acc[0][2] + acc[1][2] + bd[2], 0.f);
+            const float mx = fmaxf(z0, fmaxf(z1, z2));
+            const float e0 = expf(z0 - mx), e1 = expf(z1 - mx), e2 = expf(z2 - mx);
+            const float inv = 1.0f / (e0 + e1 + e2);
+            const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+            if (probs) {
+                probs[frame * 3 + 0] = p0;
+                probs[frame * 3 + 1] = p1;
+                probs[frame * 3 + 2] = p2;
+            }
+            // int(np.argmax(test_Y_hat[i,:])) (cnn.py:209): FIRST maximum of the probabilities as returned
+            if (labels) labels[frame] = (p0 >= p1 && p0 >= p2) ? 0 : ((p1 >= p2) ? 1 : 2);
+        }
+    }
+}
+
+template <int F>
+void pack_atab(const mdc_model* m, std::vector<unsigned short>& tab) {
+    using G = Bf16Geom<F>;
+    tab.assign((size_t)G::kATabBytes / 2, 0);
+    const float* dk = m->hk[1].data();      // (258F, 3), rows h*129F + w*F + f
+    for (int mi = 0; mi < G::kMfma; ++mi)
+        for (int kg = 0; kg < 4; ++kg)
+            for (int c = 0; c < kC; ++c)
+                for (int i = 0; i < 8; ++i) {
+                    float w = 0.f;
+                    if (mi < G::kMainMfma) {
+                        const int local = 8 * mi + i;
+                        const int j = local / (4 * F), rem = local % (4 * F), s = rem / F, ff = rem % F;
+                        const int p = 4 * j + kg, h = p >> 5, pos = 4 * (p & 31) + 1 + s;
+                        w = dk[((size_t)h * 129 * F + (size_t)pos * F + ff) * kC + c];
+                    } else {
+                        const int local = 8 * (mi - G::kMainMfma) + i;
+                        if (local < 2 * F && kg == 0) {
+                            const int h = local / F, ff = local % F;
+                            w = dk[((size_t)h * 129 * F + ff) * kC + c];      // position 0
+                        }
+                    }
+                    tab[(((size_t)mi * 4 + kg) * kC + c) * 8 + i] = f2bf(w);
+                }
+}
+
+}  // namespace
+
+// d_pack slot 2: the dense layer as MFMA A operands (bf16)
+int deployed_bf16_pack(mdc_model* m) {
+    std::vector<unsigned short> tab;
+    if (m->topo.filters == 3) pack_atab<3>(m, tab);
+    else pack_atab<10>(m, tab);
+    return upload(m, 2, tab.data(), tab.size() * sizeof(unsigned short));
+}
+
+template <int F>
+static int launch_bf16(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s) {
+    using G = Bf16Geom<F>;
+    const float* wp = static_cast<const float*>(m->d_pack[0]);
+    const uint4* atab = static_cast<const uint4*>(m->d_pack[2]);
+    const long ngroups = (n + 15) / 16;
+    long grid = (ngroups + G::kWaves - 1) / G::kWaves;
+    if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 8 staging areas)
+    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
+    hipLaunchKernelGGL(deployed_bf16_kernel<F>, dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
+    MDC_HIP(hipGetLastError());
+    return MDC_OK;
+}
+
+int deployed_bf16_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s) {
+    ProfScope ps(m, 0, s);
+    return m->topo.filters == 3 ? launch_bf16<3>(m, x, n, probs, labels, s) : launch_bf16<10>(m, x, n, probs, labels, s);
+}
+
+}  // namespace mdc

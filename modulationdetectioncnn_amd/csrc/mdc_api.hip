@@ -154,15 +154,17 @@ int mdc_finalize(mdc_model* m, int dtype) {
     for (int l = 0; l < m->nlayers; ++l)
         if (!m->have[l]) { set_error("mdc_finalize: layer %d has no weights", l); return MDC_ESTATE; }
     if (dtype != MDC_F32 && dtype != MDC_BF16 && dtype != MDC_FP8) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
-    if (dtype != MDC_F32 && m->topo.kind != MDC_KIND_VTCNN2) {
-        set_error("bf16 / fp8 are implemented for the MFMA-bound vtcnn2 family only; deployed/cnnpy nets are HBM-bound f32");
-        return MDC_ENOTSUP;
-    }
+    if (dtype == MDC_FP8 && m->topo.kind != MDC_KIND_VTCNN2) { set_error("fp8 is implemented for the vtcnn2 family only"); return MDC_ENOTSUP; }
+    if (dtype == MDC_BF16 && m->topo.kind == MDC_KIND_CNNPY) { set_error("bf16 is implemented for the vtcnn2 and deployed families only"); return MDC_ENOTSUP; }
     m->dtype = dtype;
     MDC_HIP(hipSetDevice(m->device));
     int rc;
     switch (m->topo.kind) {
-        case MDC_KIND_DEPLOYED: rc = deployed_pack(m); if (rc == MDC_OK) rc = deployed_q612_pack(m); break;
+        case MDC_KIND_DEPLOYED:
+            rc = deployed_pack(m);
+            if (rc == MDC_OK) rc = deployed_q612_pack(m);
+            if (rc == MDC_OK && dtype == MDC_BF16) rc = deployed_bf16_pack(m);
+            break;
         case MDC_KIND_VTCNN2:   rc = vtcnn2_pack(m); break;
         case MDC_KIND_CNNPY:    rc = cnnpy_pack(m); break;
         default: rc = MDC_EINVAL;
@@ -216,6 +218,7 @@ int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, floa
         set_error("mdc_forward_iq_u8: fused raw-IQ input exists for the deployed nets only; use mdc_iq_u8_to_frames + mdc_forward");
         return MDC_ENOTSUP;
     }
+    if (m->dtype != MDC_F32) { set_error("mdc_forward_iq_u8: fused raw-IQ input exists for the f32 kernels; use mdc_iq_u8_to_frames + mdc_forward"); return MDC_ENOTSUP; }
     if (n < 0) { set_error("mdc_forward_iq_u8: negative frame count"); return MDC_EINVAL; }
     if (n == 0) return MDC_OK;
     if (!iq_dev) { set_error("mdc_forward_iq_u8: null input"); return MDC_EINVAL; }

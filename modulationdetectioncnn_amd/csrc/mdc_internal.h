@@ -82,6 +82,9 @@ int upload(mdc_model* m, int idx, const void* host, size_t bytes);
 
 // ---- deployed (T1/T2): deployed.hip -------------------------------------------------
 int deployed_pack(mdc_model* m);
+// bf16 mode (dense layer on the matrix cores, lane = frame): deployed_bf16.hip
+int deployed_bf16_pack(mdc_model* m);
+int deployed_bf16_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s);
 // Q6.12 integer path of the deployed nets: deployed_q612.hip
 int deployed_q612_pack(mdc_model* m);
 int deployed_q612_forward(const mdc_model* m, const void* x, int x_is_q, int64_t n, int32_t* dense, int32_t* labels, hipStream_t s);

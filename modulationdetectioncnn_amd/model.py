@@ -45,7 +45,7 @@ class VTCNN2:
 
     def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
                  fp8_input_absmax: Optional[float] = None):
-        """dtype "f32" | "bf16" | "fp8" (the last two: vtcnn2 only).  fp8_input_absmax: the largest |I/Q sample| the
+        """dtype "f32" | "bf16" (vtcnn2, deployed) | "fp8" (vtcnn2).  fp8_input_absmax: the largest |I/Q sample| the
         fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs overflow e4m3."""
         self.topology = topology
         self.dtype = dtype
@@ -399,7 +399,7 @@ class VTCNN2:
         if t.numel() % 256:
             raise ValueError(f"{t.numel()} bytes is not a whole number of 256-byte frames")
         n, Cn = t.numel() // 256, self.topology.classes
-        if self.topology.kind == "deployed":
+        if self.topology.kind == "deployed" and self.dtype == "f32":
             probs = torch.empty((n, Cn), dtype=torch.float32, device=t.device)
             labels = torch.empty((n,), dtype=torch.int32, device=t.device)
             with torch.cuda.device(t.device):

@@ -172,3 +172,73 @@ def test_confusion_and_accuracy_match_reference_loop():
     ref = O.forward_deployed(x, *w, dtype=np.float64)
     np.testing.assert_allclose(m.confusion(x, y), O.confusion(y, ref["labels"], 3), atol=1e-12)
     assert abs(m.accuracy(x, y) - float((ref["labels"] == y).mean())) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 mode (csrc/deployed_bf16.hip): the dense layer on the matrix cores, conv outputs and dense weights rounded to
+# bf16.  Parity bar (stated here, checked below): class sums within 1e-2 of the largest |class sum| of the frame
+# (observed: a few 1e-3), probabilities within 1e-2 abs, labels equal wherever the f64 oracle's top-2 margin
+# exceeds 2e-2 of the largest class sum.  T2 has no recorded reference outputs (parity unpinned beyond the oracle).
+BF16_TOL = 1e-2
+
+
+def _bf16_check(name, x):
+    w = [a for p in load_deployed_npz(name) for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)
+    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype="bf16")
+    probs = m.predict(x)
+    lab = m.predict_classes(x)
+    np.testing.assert_allclose(probs, ref["probs"], atol=BF16_TOL)
+    assert np.isfinite(probs).all() and np.abs(probs.sum(axis=1) - 1).max() < 1e-5
+    d = ref["dense"]
+    srt = np.sort(d, axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 2 * BF16_TOL * np.maximum(np.abs(d).max(axis=1), 1e-30)
+    assert (lab[decided] == ref["labels"][decided]).all()
+    return m, probs, lab, float(decided.mean())
+
+
+@pytest.mark.parametrize("name", ["3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 1000, 65536])
+def test_bf16_mode_parity(name, n):
+    x = synthetic_frames(n, seed=2016)
+    _bf16_check(name, x)
+
+
+@pytest.mark.parametrize("name", H5_NAMES)
+def test_bf16_mode_bundled_frames_keep_their_frozen_labels(name):
+    """The reference's own frames through the bf16 kernels: same labels as the frozen f64-oracle labels wherever the
+    decision is not a near-tie, class sums within the bar."""
+    x, _meta = _frames()
+    _bf16_check(name, x)
+
+
+def test_bf16_mode_scale_bias_and_edges():
+    """Large inputs (x400, the bf16 range is f32's), a frame of zeros, and an impulse at each row end / row start:
+    exercises the zero padding at w = 0 and w = 128 and the piece boundaries of the lane = frame layout."""
+    name = "convmodrecnets_CNN2_0.5"
+    x = synthetic_frames(64, seed=5) * 400.0
+    x[1] = 0.0
+    for i, (h, s) in enumerate([(0, 0), (0, 127), (1, 0), (1, 127), (0, 3), (0, 4), (0, 63), (0, 64), (1, 31), (1, 32)]):
+        x[2 + i] = 0.0
+        x[2 + i, h, s] = 1.0
+    _bf16_check(name, x)
+    _bf16_check("3convmodrecnets_CNN2_0.5", x)
+
+
+def test_bf16_mode_is_independent_of_batch_composition_and_rejects_taps():
+    from modulationdetectioncnn_amd import _cabi
+    name = "convmodrecnets_CNN2_0.5"
+    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype="bf16")
+    x = synthetic_frames(1000, seed=8)
+    whole = m.predict(x)
+    np.testing.assert_array_equal(m.predict(x, batch_size=37), whole)                 # ragged chunks
+    np.testing.assert_array_equal(m.predict(x[5:22]), whole[5:22])                    # other neighbours in the 16-frame group
+    perm = np.random.default_rng(0).permutation(1000)
+    np.testing.assert_array_equal(m.predict(x[perm]), whole[perm])
+    with pytest.raises(_cabi.MdcError):
+        m.predict(x[:4], tap="dense")
+    # raw bytes in bf16 mode go through the conversion pass (the fused kernel is the f32 one)
+    iq = np.random.default_rng(1).integers(0, 256, size=256 * 33, dtype=np.uint8)
+    from modulationdetectioncnn_amd import frames_from_iq_u8
+    p, _l = m.predict_iq_u8(iq, 0.02 / 127.5)
+    np.testing.assert_array_equal(p, m.predict(frames_from_iq_u8(iq, 0.02 / 127.5)).cpu().numpy())

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Deployed nets, bf16 mode (dense layer on the matrix cores): frames/s of the launch variant selected with
+MDC_DEP_BF16_VARIANT (0 = 768 threads, 1 = 512 threads, 2 = 512 threads + register prefetch of the next group)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from modulationdetectioncnn_amd import VTCNN2, synthetic_frames
+
+n = 1 << 21
+x = synthetic_frames(n, seed=2016, device="cuda:0")
+probs = torch.empty((n, 3), dtype=torch.float32, device="cuda"); labels = torch.empty((n,), dtype=torch.int32, device="cuda")
+for topo in ("deployed3", "deployed10"):
+    for dt in ("f32", "bf16"):
+        m = VTCNN2.synthetic(topo, seed=2016, device=0, dtype=dt)
+        for _ in range(3): m.forward_device(x, probs, labels)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(10): m.forward_device(x, probs, labels)
+        torch.cuda.synchronize(); el = (time.perf_counter() - t) / 10
+        print(f"variant {os.environ.get('MDC_DEP_BF16_VARIANT', '0')} {topo} {dt}: {n/el:.4g} frames/s ({n*1040/el/1e12:.2f} TB/s)", flush=True)
