@@ -42,11 +42,14 @@ WORKLOADS = {
     "vtcnn2-c11-f32-n65536": ("vtcnn2", 256, 11, "f32", 1 << 16, "synthetic seed 2016"),
     "deployed3-f32-n2^20": ("deployed", 3, 3, "f32", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),
     "deployed10-f32-n2^20": ("deployed", 10, 3, "f32", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),
+    "deployed3-bf16-n2^20": ("deployed", 3, 3, "bf16", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),       # dense layer on bf16 MFMA
+    "deployed10-bf16-n2^20": ("deployed", 10, 3, "bf16", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),       # configs[2] read literally: that file, bf16
     "deployed3-f32-n2^21": ("deployed", 3, 3, "f32", 1 << 21, "3convmodrecnets_CNN2_0.5 (bundled)"),        # configs[3], T1 reading
     "cnnpy-f32-n2^20": ("cnnpy", 10, 5, "f32", 1 << 20, "synthetic seed 2016"),                           # cnn.py literal model
 }
 DEFAULT = "vtcnn2-c11-bf16-n2^20"
-EXTRAS = ["vtcnn2-c3-f32-n65536", "vtcnn2-c11-fp8-n2^20", "deployed3-f32-n2^20", "deployed10-f32-n2^20"]
+EXTRAS = ["vtcnn2-c3-f32-n65536", "vtcnn2-c11-fp8-n2^20", "deployed3-f32-n2^20", "deployed10-f32-n2^20",
+          "deployed3-bf16-n2^20", "deployed10-bf16-n2^20"]
 
 
 def make_model(name, device):

@@ -40,22 +40,26 @@ struct Bf16Geom {
     static constexpr int kExtraMfma = (2 * F + 7) / 8;                // position w = 0 of both rows
     static constexpr int kMfma = kMainMfma + kExtraMfma;
     static constexpr int kATabBytes = kMfma * 4 * kC * 16;            // A table, rows 0..2 only: [mfma][kg][class][8 bf16]
-    static constexpr int kFrameStride = 1024 + 16;                    // staged frame + pad (spreads the 16 frames over the banks)
-    static constexpr int kStageBytes = 16 * kFrameStride;             // one 16-frame group per wave
-    static constexpr int kWaves = 8;
+    static constexpr int kPairStride = 1024 + 16;                     // one DMA instruction: row r of two frames (2 x 512 B) + pad
+    static constexpr int kStageBytes = 8 * kPairStride;               // ONE ROW of a 16-frame group per wave
+    static constexpr int kWaves = 12;                                 // 3 per SIMD (8, 12 and 16 measured: 3.45 / 3.40 / 3.06e9
+                                                                      // frames/s for F = 10, the last one with spills)
     static constexpr size_t kLds = (size_t)kATabBytes + (size_t)kWaves * kStageBytes;
 };
 
-// Frames reach the lanes through a wave-private LDS staging area filled by LDS-DMA: one global_load_lds_dwordx4 per
-// frame moves 1 KiB fully coalesced (lane l -> bytes 16l..16l+15, the access pattern of deployed.hip), and lane (f, g)
-// then reads its pieces 4j + g of frame f with ds_read_b128 (+ the next piece's first sample with a ds_read_b32).
+// Frames reach the lanes through a wave-private LDS staging area filled by LDS-DMA, one ROW of the 16 frames at a
+// time: a global_load_lds_dwordx4 moves row r of two frames (2 x 512 contiguous bytes), eight of them a row of the
+// group; lane (f, g) then reads its pieces of frame f with ds_read_b128 (+ the next piece's first sample with a
+// ds_read_b32).  Row I is staged, computed (pieces j = 0..7), then row Q over the same 8 KiB; the other waves of the
+// SIMD cover a wave's DMA latency.
 // Loading the pieces straight from global memory -- 64 contiguous bytes per frame per instruction -- ran at 3.5e9
 // frames/s for F = 3 and F = 10 alike: bound by that access pattern, not by arithmetic.
 template <int F>
-__global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
-                                                               const float* __restrict__ wp, const uint4* __restrict__ atab,
-                                                               float* __restrict__ probs, int* __restrict__ labels) {
+__global__ __launch_bounds__(768, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
+                                                                const float* __restrict__ wp, const uint4* __restrict__ atab,
+                                                                float* __restrict__ probs, int* __restrict__ labels) {
     using G = Bf16Geom<F>;
+    constexpr int kPhaseUnits = G::kUnits / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* a_lds = reinterpret_cast<uint4*>(smem);
     for (int i = threadIdx.x; i < G::kATabBytes / 16; i += blockDim.x) a_lds[i] = atab[i];
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
     const int f = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* stage = smem + G::kATabBytes + wv * G::kStageBytes;
-    const unsigned char* mine = stage + f * G::kFrameStride + g * 16;      // piece 4j + g of frame f at mine + 64 j
+    // piece 4jj + g (jj = 0..7) of the staged row of frame f at mine + 64 jj
+    const unsigned char* mine = stage + (f >> 1) * G::kPairStride + (f & 1) * 512 + g * 16;
     // this lane's A row: class c = lane & 15, k-group g.  Rows 3..15 of the MFMA are never read back, so their
     // lanes simply load class 0's weights again (no zero rows in LDS, no masking)
     const uint4* a_mine = a_lds + g * kC + (f < kC ? f : 0);
@@ -78,91 +83,90 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
 
     const long ngroups = (n + 15) >> 4;
     const long gstep = (long)gridDim.x * G::kWaves;
-    auto stage_group = [&](long grp) {       // 16 x 1 KiB, frames past the end of the batch re-read the last one
+    auto stage_row = [&](long grp, int r) {       // 8 x (2 x 512 B); frames past the end of the batch re-read the last one
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const long fr = grp * 16 + i;
-            glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + lane * 4, stage + i * G::kFrameStride);
+        for (int i = 0; i < 8; ++i) {
+            const long fr = grp * 16 + 2 * i + (lane >> 5);
+            glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + r * kSamples + (lane & 31) * 4, stage + i * G::kPairStride);
         }
     };
     long grp = (long)blockIdx.x * G::kWaves + wv;
-    if (grp < ngroups) stage_group(grp);
+    if (grp < ngroups) stage_row(grp, 0);
     for (; grp < ngroups; grp += gstep) {
         const long frame = grp * 16 + f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed in its own staging area
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        float x0[2] = {0.f, 0.f};      // first sample of piece 0 / piece 32 (rows' x[0], for the g = 0 lane)
-        // LDS reads run one unit ahead of the arithmetic: pieces, next-piece samples and the A rows of unit u + 1 are
-        // requested before unit u is computed (the sched_barrier that bounds the register use would otherwise put
-        // every unit's LDS latency in front of its own arithmetic)
-        float4 c4n[G::kUnitPieces];
-        float nbn[G::kUnitPieces];
-        uint4 an[G::kUnitMfma];
-        auto read_unit = [&](int u) {
+        float x0[2] = {0.f, 0.f};      // first sample of each row (x[0], for the g = 0 lane's position w = 0)
 #pragma unroll
-            for (int q = 0; q < G::kUnitPieces; ++q) {
-                const int j = u * G::kUnitPieces + q;
-                c4n[q] = *reinterpret_cast<const float4*>(mine + 64 * j);
-                nbn[q] = *reinterpret_cast<const float*>(mine + 64 * j + 16);
-            }
+        for (int r = 0; r < 2; ++r) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed in its own staging area
+            // LDS reads run one unit ahead of the arithmetic: pieces, next-piece samples and the A rows of the next
+            // unit are requested before this one is computed (the sched_barrier that bounds the register use would
+            // otherwise put every unit's LDS latency in front of its own arithmetic)
+            float4 c4n[G::kUnitPieces];
+            float nbn[G::kUnitPieces];
+            uint4 an[G::kUnitMfma];
+            auto read_unit = [&](int up) {          // up = unit within the phase
 #pragma unroll
-            for (int mm = 0; mm < G::kUnitMfma; ++mm) an[mm] = a_mine[(u * G::kUnitMfma + mm) * 4 * kC];
-        };
-        read_unit(0);
+                for (int q = 0; q < G::kUnitPieces; ++q) {
+                    const int jj = up * G::kUnitPieces + q;
+                    c4n[q] = *reinterpret_cast<const float4*>(mine + 64 * jj);
+                    nbn[q] = *reinterpret_cast<const float*>(mine + 64 * jj + 16);
+                }
 #pragma unroll
-        for (int u = 0; u < G::kUnits; ++u) {
-            float4 c4[G::kUnitPieces];
-            float nbv[G::kUnitPieces];
-            uint4 a[G::kUnitMfma];
+                for (int mm = 0; mm < G::kUnitMfma; ++mm) an[mm] = a_mine[((r * kPhaseUnits + up) * G::kUnitMfma + mm) * 4 * kC];
+            };
+            read_unit(0);
 #pragma unroll
-            for (int q = 0; q < G::kUnitPieces; ++q) { c4[q] = c4n[q]; nbv[q] = nbn[q]; }
+            for (int up = 0; up < kPhaseUnits; ++up) {
+                const int u = r * kPhaseUnits + up;
+                float4 c4[G::kUnitPieces];
+                float nbv[G::kUnitPieces];
+                uint4 a[G::kUnitMfma];
 #pragma unroll
-            for (int mm = 0; mm < G::kUnitMfma; ++mm) a[mm] = an[mm];
-            if (u + 1 < G::kUnits) {
-                read_unit(u + 1);
-            } else {
+                for (int q = 0; q < G::kUnitPieces; ++q) { c4[q] = c4n[q]; nbv[q] = nbn[q]; }
 #pragma unroll
-                for (int mm = 0; mm < G::kExtraMfma; ++mm) an[mm] = a_mine[(G::kMainMfma + mm) * 4 * kC];      // for the w = 0 part
-            }
-            float vals[G::kUnitVals];
+                for (int mm = 0; mm < G::kUnitMfma; ++mm) a[mm] = an[mm];
+                if (up + 1 < kPhaseUnits) read_unit(up + 1);
+                float vals[G::kUnitVals];
 #pragma unroll
-            for (int q = 0; q < G::kUnitPieces; ++q) {
-                const int j = u * G::kUnitPieces + q;
-                // the last piece of a row (p & 31 == 31: g == 3, j == 7 or 15) has no next sample: x[128] = 0
-                if ((j == 7 || j == 15) && g == 3) nbv[q] = 0.f;
-                if (j == 0) x0[0] = c4[q].x;
-                if (j == 8) x0[1] = c4[q].x;
-                const float xs[5] = {c4[q].x, c4[q].y, c4[q].z, c4[q].w, nbv[q]};
+                for (int q = 0; q < G::kUnitPieces; ++q) {
+                    const int jj = up * G::kUnitPieces + q;
+                    // the last piece of a row (jj == 7, g == 3) has no next sample: x[128] = 0
+                    if (jj == 7 && g == 3) nbv[q] = 0.f;
+                    if (jj == 0) x0[r] = c4[q].x;
+                    const float xs[5] = {c4[q].x, c4[q].y, c4[q].z, c4[q].w, nbv[q]};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if constexpr (F % 2 == 0) {
+                    for (int s = 0; s < 4; ++s) {
+                        if constexpr (F % 2 == 0) {
 #pragma unroll
-                        for (int ff = 0; ff < F; ff += 2) {
-                            const f32x2 y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff + 1]}, f32x2{xs[s + 1], xs[s + 1]},
-                                                                      __builtin_elementwise_fma(f32x2{k0[ff], k0[ff + 1]}, f32x2{xs[s], xs[s]},
-                                                                                                f32x2{cb[ff], cb[ff + 1]}));
-                            vals[(q * 4 + s) * F + ff] = y.x;
-                            vals[(q * 4 + s) * F + ff + 1] = y.y;
+                            for (int ff = 0; ff < F; ff += 2) {
+                                const f32x2 y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff + 1]}, f32x2{xs[s + 1], xs[s + 1]},
+                                                                          __builtin_elementwise_fma(f32x2{k0[ff], k0[ff + 1]}, f32x2{xs[s], xs[s]},
+                                                                                                    f32x2{cb[ff], cb[ff + 1]}));
+                                vals[(q * 4 + s) * F + ff] = y.x;
+                                vals[(q * 4 + s) * F + ff + 1] = y.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int ff = 0; ff < F; ++ff) vals[(q * 4 + s) * F + ff] = fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff]));
                         }
-                    } else {
-#pragma unroll
-                        for (int ff = 0; ff < F; ++ff) vals[(q * 4 + s) * F + ff] = fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff]));
                     }
                 }
-            }
 #pragma unroll
-            for (int mm = 0; mm < G::kUnitMfma; ++mm) {
-                const int m = u * G::kUnitMfma + mm;
-                const u32x4 b = u32x4{pack2relu(vals[8 * mm + 0], vals[8 * mm + 1]), pack2relu(vals[8 * mm + 2], vals[8 * mm + 3]),
-                                      pack2relu(vals[8 * mm + 4], vals[8 * mm + 5]), pack2relu(vals[8 * mm + 6], vals[8 * mm + 7])};
-                acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mm]), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+                for (int mm = 0; mm < G::kUnitMfma; ++mm) {
+                    const int m = u * G::kUnitMfma + mm;
+                    const u32x4 b = u32x4{pack2relu(vals[8 * mm + 0], vals[8 * mm + 1]), pack2relu(vals[8 * mm + 2], vals[8 * mm + 3]),
+                                          pack2relu(vals[8 * mm + 4], vals[8 * mm + 5]), pack2relu(vals[8 * mm + 6], vals[8 * mm + 7])};
+                    acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mm]), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep each unit's values inside the unit (register budget)
             }
-            __builtin_amdgcn_sched_barrier(0);      // keep each unit's values inside the unit (register budget)
+            // every read of the staged row is done: the next row (of this group, or row I of the next) can come in
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (r == 0) stage_row(grp, 1);
+            else if (grp + gstep < ngroups) stage_row(grp + gstep, 0);
         }
-        // every read of the staging area is done: the next group's frames can come in while the rest is computed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp + gstep < ngroups) stage_group(grp + gstep);
-        {   // position w = 0 of row I (piece 0) and row Q (piece 32), owned by the g = 0 lane: y = relu(b + K1 x[0]);
+        {   // position w = 0 of row I and row Q, owned by the g = 0 lane (x[-1] = 0): y = relu(b + K1 x[0]);
             // lanes g != 0 compute the same expression on finite samples of their own and meet zero weights
             float ev[8 * G::kExtraMfma];
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                 const int m = G::kMainMfma + mm;
                 const u32x4 b = u32x4{pack2relu(ev[8 * mm + 0], ev[8 * mm + 1]), pack2relu(ev[8 * mm + 2], ev[8 * mm + 3]),
                                       pack2relu(ev[8 * mm + 4], ev[8 * mm + 5]), pack2relu(ev[8 * mm + 6], ev[8 * mm + 7])};
-                const uint4 a = an[mm];
+                const uint4 a = a_mine[m * 4 * kC];
                 acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
             }
         }
@@ -244,7 +248,7 @@ static int launch_bf16(const mdc_model* m, const float* x, int64_t n, float* pro
     const uint4* atab = static_cast<const uint4*>(m->d_pack[2]);
     const long ngroups = (n + 15) / 16;
     long grid = (ngroups + G::kWaves - 1) / G::kWaves;
-    if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 8 staging areas)
+    if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 16 staging areas)
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
     hipLaunchKernelGGL(deployed_bf16_kernel<F>, dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
     MDC_HIP(hipGetLastError());

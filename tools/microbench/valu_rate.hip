@@ -15,6 +15,8 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink) 
     float s = 1.0001f, t = 0.5f;
     f32x2 s2 = f32x2{1.0001f, 1.0002f}, t2 = f32x2{0.5f, 0.25f};
     asm volatile("" : "+v"(s), "+v"(t), "+v"(s2), "+v"(t2));
+    f32x2 ks = f32x2{1.0001f, 0.9999f};
+    asm volatile("" : "+s"(ks));
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
@@ -24,6 +26,10 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink) 
             if (MODE == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(p[i]) : "v"(s2), "v"(t2));
             if (MODE == 3) { asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(t)); asm volatile("v_max_f32 %0, %0, %1" : "+v"(p[i][0]) : "v"(t)); }
             if (MODE == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(s2));
+            // the forms the deployed bf16 kernel uses: tap pair in an SGPR pair, sample broadcast from one half of a VGPR pair
+            if (MODE == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "s"(ks), "v"(t2));
+            if (MODE == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p[i]) : "s"(ks), "v"(t2));
+            if (MODE == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(p[i]) : "s"(ks), "v"(t2), "v"(s2));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -50,8 +56,10 @@ int main() {
     unsigned long long* d; float* sink;
     hipMalloc(&d, 256 * 8); hipMalloc(&sink, 64);
     for (int threads : {256, 512, 1024}) {
-        if (threads == 256) { run<0>("v_fma_f32", 256, d, sink); run<1>("v_pk_fma_f32", 256, d, sink); run<2>("v_pk_fma_f32 (broadcast src)", 256, d, sink); run<3>("v_max_f32", 256, d, sink); run<4>("v_pk_mul_f32", 256, d, sink); }
-        if (threads == 512) { run<0>("v_fma_f32", 512, d, sink); run<1>("v_pk_fma_f32", 512, d, sink); }
+        if (threads == 256) { run<0>("v_fma_f32", 256, d, sink); run<1>("v_pk_fma_f32", 256, d, sink); run<2>("v_pk_fma_f32 (broadcast src)", 256, d, sink); run<3>("v_max_f32", 256, d, sink); run<4>("v_pk_mul_f32", 256, d, sink);
+                              run<5>("v_pk_fma_f32 (sgpr pair src0)", 256, d, sink); run<6>("v_pk_fma_f32 (sgpr + broadcast)", 256, d, sink);
+                              run<7>("v_pk_fma_f32 (sgpr+bcast, independent)", 256, d, sink); }
+        if (threads == 512) { run<0>("v_fma_f32", 512, d, sink); run<1>("v_pk_fma_f32", 512, d, sink); run<6>("v_pk_fma_f32 (sgpr + broadcast)", 512, d, sink); }
         if (threads == 1024) { run<0>("v_fma_f32", 1024, d, sink); run<1>("v_pk_fma_f32", 1024, d, sink); }
     }
     return 0;
