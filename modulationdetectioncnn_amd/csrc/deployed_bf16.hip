@@ -41,21 +41,22 @@ struct Bf16Geom {
     static constexpr int kMfma = kMainMfma + kExtraMfma;
     static constexpr int kATabBytes = kMfma * 4 * kC * 16;            // A table, rows 0..2 only: [mfma][kg][class][8 bf16]
     static constexpr int kPairStride = 1024 + 16;                     // one DMA instruction: row r of two frames (2 x 512 B) + pad
-    static constexpr int kStageBytes = 8 * kPairStride;               // ONE ROW of a 16-frame group per wave
-    static constexpr int kWaves = 12;                                 // 3 per SIMD (8, 12 and 16 measured: 3.45 / 3.40 / 3.06e9
-                                                                      // frames/s for F = 10, the last one with spills)
-    static constexpr size_t kLds = (size_t)kATabBytes + (size_t)kWaves * kStageBytes;
+    static constexpr int kStageBytes = 8 * kPairStride;               // ONE ROW of a 16-frame group
+    static constexpr int kWaves = 8;                                  // 2 per SIMD, each with TWO row buffers (8, 12, 16 waves with
+                                                                      // one buffer: 3.45 / 3.40 / 3.06e9 frames/s for F = 10)
+    static constexpr size_t kLds = (size_t)kATabBytes + (size_t)kWaves * 2 * kStageBytes;
 };
 
 // Frames reach the lanes through a wave-private LDS staging area filled by LDS-DMA, one ROW of the 16 frames at a
 // time: a global_load_lds_dwordx4 moves row r of two frames (2 x 512 contiguous bytes), eight of them a row of the
 // group; lane (f, g) then reads its pieces of frame f with ds_read_b128 (+ the next piece's first sample with a
-// ds_read_b32).  Row I is staged, computed (pieces j = 0..7), then row Q over the same 8 KiB; the other waves of the
-// SIMD cover a wave's DMA latency.
+// ds_read_b32).  Two row buffers per wave: while row I (pieces j = 0..7) is computed row Q is in flight, while row Q
+// is computed row I of the wave's next group is -- without the DMA the F = 10 kernel runs at 4.25e9 frames/s, with a
+// single buffer (DMA latency exposed twice per group) at 3.4e9.
 // Loading the pieces straight from global memory -- 64 contiguous bytes per frame per instruction -- ran at 3.5e9
 // frames/s for F = 3 and F = 10 alike: bound by that access pattern, not by arithmetic.
 template <int F>
-__global__ __launch_bounds__(768, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
+__global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
                                                                 const float* __restrict__ wp, const uint4* __restrict__ atab,
                                                                 float* __restrict__ probs, int* __restrict__ labels) {
     using G = Bf16Geom<F>;
@@ -68,9 +69,9 @@ __global__ __launch_bounds__(768, 1) void deployed_bf16_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int f = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* stage = smem + G::kATabBytes + wv * G::kStageBytes;
-    // piece 4jj + g (jj = 0..7) of the staged row of frame f at mine + 64 jj
-    const unsigned char* mine = stage + (f >> 1) * G::kPairStride + (f & 1) * 512 + g * 16;
+    unsigned char* stage = smem + G::kATabBytes + wv * 2 * G::kStageBytes;      // row r of a group goes to buffer r
+    // piece 4jj + g (jj = 0..7) of the staged row r of frame f at mine0 + r * kStageBytes + 64 jj
+    const unsigned char* mine0 = stage + (f >> 1) * G::kPairStride + (f & 1) * 512 + g * 16;
     // this lane's A row: class c = lane & 15, k-group g.  Rows 3..15 of the MFMA are never read back, so their
     // lanes simply load class 0's weights again (no zero rows in LDS, no masking)
     const uint4* a_mine = a_lds + g * kC + (f < kC ? f : 0);
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(768, 1) void deployed_bf16_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long fr = grp * 16 + 2 * i + (lane >> 5);
-            glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + r * kSamples + (lane & 31) * 4, stage + i * G::kPairStride);
+            glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + r * kSamples + (lane & 31) * 4, stage + r * G::kStageBytes + i * G::kPairStride);
         }
     };
     long grp = (long)blockIdx.x * G::kWaves + wv;
@@ -98,7 +99,14 @@ __global__ __launch_bounds__(768, 1) void deployed_bf16_kernel(const float* __re
         float x0[2] = {0.f, 0.f};      // first sample of each row (x[0], for the g = 0 lane's position w = 0)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed in its own staging area
+            const unsigned char* mine = mine0 + r * G::kStageBytes;
+            // the row after this one goes into the other buffer now (its last reader finished a row ago, lgkmcnt(0)
+            // below); then wait until only those eight DMA instructions are outstanding: this row has landed
+            const bool more = r == 0 || grp + gstep < ngroups;
+            if (r == 0) stage_row(grp, 1);
+            else if (more) stage_row(grp + gstep, 0);
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // LDS reads run one unit ahead of the arithmetic: pieces, next-piece samples and the A rows of the next
             // unit are requested before this one is computed (the sched_barrier that bounds the register use would
             // otherwise put every unit's LDS latency in front of its own arithmetic)
@@ -161,10 +169,7 @@ __global__ __launch_bounds__(768, 1) void deployed_bf16_kernel(const float* __re
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep each unit's values inside the unit (register budget)
             }
-            // every read of the staged row is done: the next row (of this group, or row I of the next) can come in
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (r == 0) stage_row(grp, 1);
-            else if (grp + gstep < ngroups) stage_row(grp + gstep, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of this row's buffer is done
         }
         {   // position w = 0 of row I and row Q, owned by the g = 0 lane (x[-1] = 0): y = relu(b + K1 x[0]);
             // lanes g != 0 compute the same expression on finite samples of their own and meet zero weights
@@ -248,7 +253,7 @@ static int launch_bf16(const mdc_model* m, const float* x, int64_t n, float* pro
     const uint4* atab = static_cast<const uint4*>(m->d_pack[2]);
     const long ngroups = (n + 15) / 16;
     long grid = (ngroups + G::kWaves - 1) / G::kWaves;
-    if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 16 staging areas)
+    if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 8 x 2 row buffers)
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
     hipLaunchKernelGGL(deployed_bf16_kernel<F>, dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
     MDC_HIP(hipGetLastError());
