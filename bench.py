@@ -107,7 +107,8 @@ def dominant_roofline(m, x, probs, labels, steps):
         ach = by / (avg_ms * 1e-3) / 1e9
         rl = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
               "frac": ach / PEAK_HBM_GBS,
-              "traffic": measured_traffic(f"{name}/F{topo.filters}" if topo.kind == "deployed" else name, frames_per_launch),
+              "traffic": measured_traffic((f"{name}/F{topo.filters}" + ("/bf16" if m.dtype == "bf16" else "")) if topo.kind == "deployed" else name,
+                                          frames_per_launch),
               "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
     return rl, kernels
 
