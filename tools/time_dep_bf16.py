@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Deployed nets, bf16 mode (dense layer on the matrix cores): frames/s of the launch variant selected with
-MDC_DEP_BF16_VARIANT (0 = 768 threads, 1 = 512 threads, 2 = 512 threads + register prefetch of the next group)."""
+"""Deployed nets: frames/s of the f32 kernels and of the bf16 mode (dense layer on the matrix cores) on 2^21 frames."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from modulationdetectioncnn_amd import VTCNN2, synthetic_frames
@@ -15,4 +14,4 @@ for topo in ("deployed3", "deployed10"):
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(10): m.forward_device(x, probs, labels)
         torch.cuda.synchronize(); el = (time.perf_counter() - t) / 10
-        print(f"variant {os.environ.get('MDC_DEP_BF16_VARIANT', '0')} {topo} {dt}: {n/el:.4g} frames/s ({n*1040/el/1e12:.2f} TB/s)", flush=True)
+        print(f"{topo} {dt}: {n/el:.4g} frames/s ({n*1040/el/1e12:.2f} TB/s)", flush=True)
