@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdc.so")
 
 KIND_DEPLOYED, KIND_VTCNN2, KIND_CNNPY = 1, 2, 3
-F32, BF16, FP8 = 0, 1, 2
+F32, BF16, FP8, F16 = 0, 1, 2, 3
 TAP_NONE, TAP_CONV, TAP_FLAT, TAP_DENSE, TAP_HIDDEN = 0, 1, 2, 3, 4
 
 EXPORTS = [

@@ -15,6 +15,10 @@
 // only the g = 0 lane of a frame owns (the other lanes' weights for those slots are zero).
 // VALU per frame: 2 v_pk_fma_f32 + cvt_pk + pk_max per two outputs = 81 instead of ~180; the dense part is 8F + 1..3
 // MFMAs per 16 frames with A (three non-zero rows) read from a table in LDS.
+// HALF = true (MDC_F16): the same kernel with IEEE f16 instead of bf16 operands -- and then the conv itself runs in
+// packed f16 (v_pk_fma_f16 on 32-bit registers: two filters per instruction at the plain VALU rate, ReLU = one
+// v_pk_max_f16, no conversion before the MFMA), which is what lifts the F = 10 net off the v_pk_fma_f32 bound.  f16
+// keeps 11 significant bits (bf16: 8) but only ~5 decades of range: conv outputs must stay below 65,504.
 // Numerics: conv in f32 exactly as the f32 kernel; conv outputs and dense weights rounded to bf16 (RNE), products
 // accumulated in f32 by the MFMA; bias, ReLU, softmax, first-max argmax in f32 as in deployed.hip.
 #include "vtcnn2_bf16_common.h"
@@ -55,7 +59,10 @@ struct Bf16Geom {
 // single buffer (DMA latency exposed twice per group) at 3.4e9.
 // Loading the pieces straight from global memory -- 64 contiguous bytes per frame per instruction -- ran at 3.5e9
 // frames/s for F = 3 and F = 10 alike: bound by that access pattern, not by arithmetic.
-template <int F>
+using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+template <int F, bool HALF>
 __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
                                                                 const float* __restrict__ wp, const uint4* __restrict__ atab,
                                                                 float* __restrict__ probs, int* __restrict__ labels) {
@@ -81,6 +88,15 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
     for (int i = 0; i < F; ++i) { k0[i] = wp[3 * i + 0]; k1[i] = wp[3 * i + 1]; cb[i] = wp[3 * i + 2]; }
 #pragma unroll
     for (int c = 0; c < kC; ++c) bd[c] = wp[3 * F + c];
+    // f16 mode: taps and bias as f16 pairs (filters f, f+1); an odd F gets a zero partner
+    h16x2 k0h[(F + 1) / 2], k1h[(F + 1) / 2], cbh[(F + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (F + 1) / 2; ++i) {
+        const bool two = 2 * i + 1 < F;
+        k0h[i] = h16x2{(_Float16)k0[2 * i], two ? (_Float16)k0[2 * i + (two ? 1 : 0)] : (_Float16)0.f};
+        k1h[i] = h16x2{(_Float16)k1[2 * i], two ? (_Float16)k1[2 * i + (two ? 1 : 0)] : (_Float16)0.f};
+        cbh[i] = h16x2{(_Float16)cb[2 * i], two ? (_Float16)cb[2 * i + (two ? 1 : 0)] : (_Float16)0.f};
+    }
 
     const long ngroups = (n + 15) >> 4;
     const long gstep = (long)gridDim.x * G::kWaves;
@@ -135,37 +151,65 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
 #pragma unroll
                 for (int mm = 0; mm < G::kUnitMfma; ++mm) a[mm] = an[mm];
                 if (up + 1 < kPhaseUnits) read_unit(up + 1);
-                float vals[G::kUnitVals];
+                // the unit's conv outputs, packed two per word in production order (position, filter): bf16 after an f32
+                // conv, or f16 straight out of a packed-f16 conv
+                unsigned pk[G::kUnitVals / 2];
+                if constexpr (!HALF) {
+                    float vals[G::kUnitVals];
 #pragma unroll
-                for (int q = 0; q < G::kUnitPieces; ++q) {
-                    const int jj = up * G::kUnitPieces + q;
-                    // the last piece of a row (jj == 7, g == 3) has no next sample: x[128] = 0
-                    if (jj == 7 && g == 3) nbv[q] = 0.f;
-                    if (jj == 0) x0[r] = c4[q].x;
-                    const float xs[5] = {c4[q].x, c4[q].y, c4[q].z, c4[q].w, nbv[q]};
+                    for (int q = 0; q < G::kUnitPieces; ++q) {
+                        const int jj = up * G::kUnitPieces + q;
+                        // the last piece of a row (jj == 7, g == 3) has no next sample: x[128] = 0
+                        if (jj == 7 && g == 3) nbv[q] = 0.f;
+                        if (jj == 0) x0[r] = c4[q].x;
+                        const float xs[5] = {c4[q].x, c4[q].y, c4[q].z, c4[q].w, nbv[q]};
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        if constexpr (F % 2 == 0) {
+                        for (int s = 0; s < 4; ++s) {
+                            if constexpr (F % 2 == 0) {
 #pragma unroll
-                            for (int ff = 0; ff < F; ff += 2) {
-                                const f32x2 y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff + 1]}, f32x2{xs[s + 1], xs[s + 1]},
-                                                                          __builtin_elementwise_fma(f32x2{k0[ff], k0[ff + 1]}, f32x2{xs[s], xs[s]},
-                                                                                                    f32x2{cb[ff], cb[ff + 1]}));
-                                vals[(q * 4 + s) * F + ff] = y.x;
-                                vals[(q * 4 + s) * F + ff + 1] = y.y;
+                                for (int ff = 0; ff < F; ff += 2) {
+                                    const f32x2 y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff + 1]}, f32x2{xs[s + 1], xs[s + 1]},
+                                                                              __builtin_elementwise_fma(f32x2{k0[ff], k0[ff + 1]}, f32x2{xs[s], xs[s]},
+                                                                                                        f32x2{cb[ff], cb[ff + 1]}));
+                                    vals[(q * 4 + s) * F + ff] = y.x;
+                                    vals[(q * 4 + s) * F + ff + 1] = y.y;
+                                }
+                            } else {
+#pragma unroll
+                                for (int ff = 0; ff < F; ++ff) vals[(q * 4 + s) * F + ff] = fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff]));
                             }
-                        } else {
-#pragma unroll
-                            for (int ff = 0; ff < F; ++ff) vals[(q * 4 + s) * F + ff] = fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff]));
                         }
                     }
+#pragma unroll
+                    for (int i = 0; i < G::kUnitVals / 2; ++i) pk[i] = pack2relu(vals[2 * i], vals[2 * i + 1]);
+                } else {
+                    _Float16 hv[G::kUnitVals];
+#pragma unroll
+                    for (int q = 0; q < G::kUnitPieces; ++q) {
+                        const int jj = up * G::kUnitPieces + q;
+                        if (jj == 7 && g == 3) nbv[q] = 0.f;
+                        if (jj == 0) x0[r] = c4[q].x;
+                        const _Float16 xh[5] = {(_Float16)c4[q].x, (_Float16)c4[q].y, (_Float16)c4[q].z, (_Float16)c4[q].w, (_Float16)nbv[q]};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int ff = 0; ff < F; ff += 2) {
+                                h16x2 y = __builtin_elementwise_fma(k1h[ff / 2], h16x2{xh[s + 1], xh[s + 1]},
+                                                                    __builtin_elementwise_fma(k0h[ff / 2], h16x2{xh[s], xh[s]}, cbh[ff / 2]));
+                                y = __builtin_elementwise_max(y, h16x2{(_Float16)0.f, (_Float16)0.f});
+                                hv[(q * 4 + s) * F + ff] = y.x;
+                                if (ff + 1 < F) hv[(q * 4 + s) * F + ff + 1] = y.y;
+                            }
+                    }
+#pragma unroll
+                    for (int i = 0; i < G::kUnitVals / 2; ++i) pk[i] = __builtin_bit_cast(unsigned, h16x2{hv[2 * i], hv[2 * i + 1]});
                 }
 #pragma unroll
                 for (int mm = 0; mm < G::kUnitMfma; ++mm) {
                     const int m = u * G::kUnitMfma + mm;
-                    const u32x4 b = u32x4{pack2relu(vals[8 * mm + 0], vals[8 * mm + 1]), pack2relu(vals[8 * mm + 2], vals[8 * mm + 3]),
-                                          pack2relu(vals[8 * mm + 4], vals[8 * mm + 5]), pack2relu(vals[8 * mm + 6], vals[8 * mm + 7])};
-                    acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mm]), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+                    const u32x4 b = u32x4{pk[4 * mm + 0], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]};
+                    if constexpr (HALF) acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a[mm]), __builtin_bit_cast(h16x8, b), acc[m & 1], 0, 0, 0);
+                    else acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mm]), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep each unit's values inside the unit (register budget)
             }
@@ -184,10 +228,33 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
 #pragma unroll
             for (int mm = 0; mm < G::kExtraMfma; ++mm) {
                 const int m = G::kMainMfma + mm;
-                const u32x4 b = u32x4{pack2relu(ev[8 * mm + 0], ev[8 * mm + 1]), pack2relu(ev[8 * mm + 2], ev[8 * mm + 3]),
-                                      pack2relu(ev[8 * mm + 4], ev[8 * mm + 5]), pack2relu(ev[8 * mm + 6], ev[8 * mm + 7])};
                 const uint4 a = a_mine[m * 4 * kC];
-                acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+                if constexpr (HALF) {
+                    // f16 mode: the same values through f16 arithmetic (x and taps rounded to f16 as in the main part)
+                    unsigned w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        _Float16 e[2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int idx = 8 * mm + 2 * i + k;      // slot: row idx / F, filter idx % F
+                            _Float16 v = (_Float16)0.f;
+                            if (idx < 2 * F) {
+                                const int ff = idx % F;
+                                const _Float16 kk = (ff & 1) ? k1h[ff / 2].y : k1h[ff / 2].x, bb = (ff & 1) ? cbh[ff / 2].y : cbh[ff / 2].x;
+                                v = __builtin_fmaf16(kk, (_Float16)x0[idx / F], bb);
+                                v = v > (_Float16)0.f ? v : (_Float16)0.f;
+                            }
+                            e[k] = v;
+                        }
+                        w[i] = __builtin_bit_cast(unsigned, h16x2{e[0], e[1]});
+                    }
+                    acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, u32x4{w[0], w[1], w[2], w[3]}), acc[m & 1], 0, 0, 0);
+                } else {
+                    const u32x4 b = u32x4{pack2relu(ev[8 * mm + 0], ev[8 * mm + 1]), pack2relu(ev[8 * mm + 2], ev[8 * mm + 3]),
+                                          pack2relu(ev[8 * mm + 4], ev[8 * mm + 5]), pack2relu(ev[8 * mm + 6], ev[8 * mm + 7])};
+                    acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+                }
             }
         }
         // D rows 0..2 (the classes) of column f live in lanes 0..15 (kg = 0), registers 0..2
@@ -208,6 +275,30 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
             if (labels) labels[frame] = (p0 >= p1 && p0 >= p2) ? 0 : ((p1 >= p2) ? 1 : 2);
         }
     }
+}
+
+// host f32 -> IEEE f16 (RNE, saturating to +-inf like the hardware conversion)
+inline unsigned short f2h(float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xFF) - 127 + 15;
+    unsigned man = u & 0x7FFFFFu;
+    if (((u >> 23) & 0xFF) == 0xFF) return (unsigned short)(sign | 0x7C00u | (man ? 0x200u : 0u));
+    if (e >= 31) return (unsigned short)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (unsigned short)sign;
+        man |= 0x800000u;
+        const int shift = 14 - e;
+        unsigned h = man >> shift;
+        const unsigned rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1))) ++h;
+        return (unsigned short)(sign | h);
+    }
+    unsigned h = ((unsigned)e << 10) | (man >> 13);
+    const unsigned rem = man & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+    return (unsigned short)(sign | h);
 }
 
 template <int F>
@@ -232,7 +323,7 @@ void pack_atab(const mdc_model* m, std::vector<unsigned short>& tab) {
                             w = dk[((size_t)h * 129 * F + ff) * kC + c];      // position 0
                         }
                     }
-                    tab[(((size_t)mi * 4 + kg) * kC + c) * 8 + i] = f2bf(w);
+                    tab[(((size_t)mi * 4 + kg) * kC + c) * 8 + i] = m->dtype == MDC_F16 ? f2h(w) : f2bf(w);
                 }
 }
 
@@ -254,8 +345,13 @@ static int launch_bf16(const mdc_model* m, const float* x, int64_t n, float* pro
     const long ngroups = (n + 15) / 16;
     long grid = (ngroups + G::kWaves - 1) / G::kWaves;
     if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 8 x 2 row buffers)
-    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
-    hipLaunchKernelGGL(deployed_bf16_kernel<F>, dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
+    if (m->dtype == MDC_F16) {
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
+        hipLaunchKernelGGL((deployed_bf16_kernel<F, true>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
+    } else {
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
+        hipLaunchKernelGGL((deployed_bf16_kernel<F, false>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
+    }
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

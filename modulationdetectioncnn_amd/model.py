@@ -28,7 +28,7 @@ from .topology import Topology, synthetic_weights
 
 _KIND = {"deployed": _cabi.KIND_DEPLOYED, "vtcnn2": _cabi.KIND_VTCNN2, "cnnpy": _cabi.KIND_CNNPY}
 _DTYPE = {"f32": _cabi.F32, "fp32": _cabi.F32, "float32": _cabi.F32, "bf16": _cabi.BF16, "bfloat16": _cabi.BF16,
-          "fp8": _cabi.FP8}
+          "fp8": _cabi.FP8, "f16": _cabi.F16, "fp16": _cabi.F16, "float16": _cabi.F16}
 _TAP = {None: _cabi.TAP_NONE, "conv": _cabi.TAP_CONV, "flat": _cabi.TAP_FLAT, "dense": _cabi.TAP_DENSE,
         "hidden": _cabi.TAP_HIDDEN}
 
@@ -45,7 +45,7 @@ class VTCNN2:
 
     def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
                  fp8_input_absmax: Optional[float] = None):
-        """dtype "f32" | "bf16" (vtcnn2, deployed) | "fp8" (vtcnn2).  fp8_input_absmax: the largest |I/Q sample| the
+        """dtype "f32" | "bf16" (vtcnn2, deployed) | "f16" (deployed) | "fp8" (vtcnn2).  fp8_input_absmax: the largest |I/Q sample| the
         fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs overflow e4m3."""
         self.topology = topology
         self.dtype = dtype

@@ -147,6 +147,8 @@ def test_empty_and_errors():
         VTCNN2.from_npz(os.path.join(GOLDEN, "weights", "3convmodrecnets_CNN2_0.5.npz"), dtype="fp8").predict(np.zeros((1, 2, 128), np.float32))
     with pytest.raises(MdcError):       # bf16: vtcnn2 and deployed, not the cnn.py literal model
         VTCNN2.synthetic("cnnpy", classes=5, dtype="bf16").predict(np.zeros((1, 2, 128), np.float32))
+    with pytest.raises(MdcError):       # f16: the deployed nets only
+        VTCNN2.synthetic("vtcnn2", classes=11, dtype="f16").predict(np.zeros((1, 2, 128), np.float32))
 
 
 def test_txt_weights_load_and_classify(tmp_path):
@@ -184,10 +186,10 @@ def test_confusion_and_accuracy_match_reference_loop():
 BF16_TOL = 1e-2
 
 
-def _bf16_check(name, x):
+def _bf16_check(name, x, dtype="bf16"):
     w = [a for p in load_deployed_npz(name) for a in p]
     ref = O.forward_deployed(x, *w, dtype=np.float64)
-    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype="bf16")
+    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype=dtype)
     probs = m.predict(x)
     lab = m.predict_classes(x)
     np.testing.assert_allclose(probs, ref["probs"], atol=BF16_TOL)
@@ -199,19 +201,35 @@ def _bf16_check(name, x):
     return m, probs, lab, float(decided.mean())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("name", ["3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 1000, 65536])
-def test_bf16_mode_parity(name, n):
+def test_bf16_mode_parity(name, n, dtype):
+    """Both 16-bit modes against the same bar (f16 -- 11 significant bits, conv in packed f16 -- lands well inside it)."""
     x = synthetic_frames(n, seed=2016)
-    _bf16_check(name, x)
+    _bf16_check(name, x, dtype)
 
 
+def test_f16_mode_is_tighter_than_bf16():
+    """f16 operands keep three more bits than bf16: its class sums must sit closer to the f64 oracle."""
+    name = "convmodrecnets_CNN2_0.5"
+    x = synthetic_frames(4096, seed=31)
+    w = [a for p in load_deployed_npz(name) for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)["probs"]
+    err = {}
+    for dt in ("bf16", "f16"):
+        m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype=dt)
+        err[dt] = float(np.abs(m.predict(x) - ref).max())
+    assert err["f16"] < err["bf16"] and err["f16"] < 3e-3, err
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("name", H5_NAMES)
-def test_bf16_mode_bundled_frames_keep_their_frozen_labels(name):
+def test_bf16_mode_bundled_frames_keep_their_frozen_labels(name, dtype):
     """The reference's own frames through the bf16 kernels: same labels as the frozen f64-oracle labels wherever the
     decision is not a near-tie, class sums within the bar."""
     x, _meta = _frames()
-    _bf16_check(name, x)
+    _bf16_check(name, x, dtype)
 
 
 def test_bf16_mode_scale_bias_and_edges():
@@ -223,14 +241,16 @@ def test_bf16_mode_scale_bias_and_edges():
     for i, (h, s) in enumerate([(0, 0), (0, 127), (1, 0), (1, 127), (0, 3), (0, 4), (0, 63), (0, 64), (1, 31), (1, 32)]):
         x[2 + i] = 0.0
         x[2 + i, h, s] = 1.0
-    _bf16_check(name, x)
-    _bf16_check("3convmodrecnets_CNN2_0.5", x)
+    for dt in ("bf16", "f16"):          # x400 keeps the conv outputs (~1e2) far below the f16 range
+        _bf16_check(name, x, dt)
+        _bf16_check("3convmodrecnets_CNN2_0.5", x, dt)
 
 
-def test_bf16_mode_is_independent_of_batch_composition_and_rejects_taps():
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_bf16_mode_is_independent_of_batch_composition_and_rejects_taps(dtype):
     from modulationdetectioncnn_amd import _cabi
     name = "convmodrecnets_CNN2_0.5"
-    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype="bf16")
+    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype=dtype)
     x = synthetic_frames(1000, seed=8)
     whole = m.predict(x)
     np.testing.assert_array_equal(m.predict(x, batch_size=37), whole)                 # ragged chunks
