@@ -44,12 +44,14 @@ WORKLOADS = {
     "deployed10-f32-n2^20": ("deployed", 10, 3, "f32", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),
     "deployed3-bf16-n2^20": ("deployed", 3, 3, "bf16", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),       # dense layer on bf16 MFMA
     "deployed10-bf16-n2^20": ("deployed", 10, 3, "bf16", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),       # configs[2] read literally: that file, bf16
+    "deployed3-f16-n2^20": ("deployed", 3, 3, "f16", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),         # conv in packed f16, dense on f16 MFMA
+    "deployed10-f16-n2^20": ("deployed", 10, 3, "f16", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),
     "deployed3-f32-n2^21": ("deployed", 3, 3, "f32", 1 << 21, "3convmodrecnets_CNN2_0.5 (bundled)"),        # configs[3], T1 reading
     "cnnpy-f32-n2^20": ("cnnpy", 10, 5, "f32", 1 << 20, "synthetic seed 2016"),                           # cnn.py literal model
 }
 DEFAULT = "vtcnn2-c11-bf16-n2^20"
 EXTRAS = ["vtcnn2-c3-f32-n65536", "vtcnn2-c11-fp8-n2^20", "deployed3-f32-n2^20", "deployed10-f32-n2^20",
-          "deployed3-bf16-n2^20", "deployed10-bf16-n2^20"]
+          "deployed3-bf16-n2^20", "deployed10-bf16-n2^20", "deployed3-f16-n2^20", "deployed10-f16-n2^20"]
 
 
 def make_model(name, device):
@@ -107,7 +109,7 @@ def dominant_roofline(m, x, probs, labels, steps):
         ach = by / (avg_ms * 1e-3) / 1e9
         rl = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
               "frac": ach / PEAK_HBM_GBS,
-              "traffic": measured_traffic((f"{name}/F{topo.filters}" + ("/bf16" if m.dtype == "bf16" else "")) if topo.kind == "deployed" else name,
+              "traffic": measured_traffic((f"{name}/F{topo.filters}" + ("/" + m.dtype if m.dtype != "f32" else "")) if topo.kind == "deployed" else name,
                                           frames_per_launch),
               "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
     return rl, kernels
@@ -264,7 +266,7 @@ def main():
     out = {
         "metric": "I/Q frames/sec (2x128, VT-CNN2, batch=2^20)", "value": total_frames / el, "unit": "frames/s",
         "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8"}[dtype],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8", "f16": "f16"}[dtype],
         "data": "synthetic N(0,5e-3) f32 frames resident in HBM; " + weights,
         "config": {"workload": name, "topology": kind, "classes": classes, "frames_per_gpu": n,
                    "global_batch": n * ngpu, "parallelism": f"batch-shard x{ngpu} (no collective)",
