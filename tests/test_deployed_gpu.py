@@ -264,3 +264,23 @@ def test_bf16_mode_is_independent_of_batch_composition_and_rejects_taps(dtype):
     from modulationdetectioncnn_amd import frames_from_iq_u8
     p, _l = m.predict_iq_u8(iq, 0.02 / 127.5)
     np.testing.assert_array_equal(p, m.predict(frames_from_iq_u8(iq, 0.02 / 127.5)).cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_modes_keep_an_out_of_range_frame_to_itself(dtype):
+    """A frame far outside the f16 range (x = 1e6: conv outputs overflow f16 to inf) or full of NaN must not change
+    any other frame of its 16-frame group: MFMA columns are independent, zero weights never meet the bad values of
+    another frame."""
+    name = "convmodrecnets_CNN2_0.5"
+    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype=dtype)
+    x = synthetic_frames(64, seed=13)
+    clean = m.predict(x)
+    bad = x.copy()
+    bad[5] *= 2e8
+    bad[20] = np.nan
+    out = m.predict(bad)
+    keep = np.ones(64, bool)
+    keep[[5, 20]] = False
+    np.testing.assert_array_equal(out[keep], clean[keep])
+    if dtype == "bf16":          # bf16 has f32's range: a huge frame still classifies (softmax saturates to one class)
+        assert np.isfinite(out[5]).all() and abs(out[5].sum() - 1) < 1e-5
