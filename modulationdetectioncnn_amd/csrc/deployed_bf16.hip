@@ -1,26 +1,29 @@
-// Deployed single-conv nets (T1: F=3, T2: F=10) with the dense layer on the bf16 matrix cores (MDC_BF16).
+// Deployed single-conv nets (T1: F=3, T2: F=10) with the dense layer on the matrix cores: MDC_BF16 and MDC_F16.
 //
 // Why: the f32 kernel (deployed.hip) is one wave = one frame, each lane multiplying ITS conv outputs by ITS dense
-// weights on the vector ALU -- 3 FMAs per conv output, which for F = 10 (2,580 outputs x 3 classes per frame) makes the
-// kernel VALU-bound at a third of the HBM roofline.  Here the dense layer is a GEMM on v_mfma_f32_16x16x32_bf16:
+// weights on the vector ALU -- 3 FMAs per conv output, which for F = 10 (2,580 outputs x 3 classes per frame) makes
+// the kernel VALU-bound at a third of the HBM roofline.  Here the dense layer is a GEMM on v_mfma_f32_16x16x32_bf16
+// (or _f16):
 //     D[class][frame] += A[class][k] * B[k][frame],   k = one conv output of the frame,
 // which needs "lane = frame": the MFMA's B operand of lane (n = lane & 15, kg = lane >> 4) is 8 k-values of column
 // (frame) n.  So a wave takes 16 frames at a time and lane (f, g) owns a QUARTER of frame f: the sixteen 4-sample
-// pieces p = 4j + g (j = 0..15) of the frame's 64 pieces (row I = pieces 0..31, row Q = 32..63), read from a staging
-// area in LDS that LDS-DMA fills 1 KiB (one frame) per instruction, every byte of the batch exactly once.  For each piece the lane computes its 4 conv positions x F filters in f32 (same fma chain
-// as deployed.hip: fma(K1, x[w], fma(K0, x[w-1], b))), applies ReLU on the packed bf16 halves, and the values ARE the
-// B operand (k order = order of production; the host lays the dense weights out to match, zero rows for classes
-// 3..15).  The sample x[w] a piece lacks for its last position is the first sample of the NEXT piece: one extra
-// ds_read_b32, zero at the row end.  Position w = 0 of each row (x[-1] = 0) is an extra 2F values that
-// only the g = 0 lane of a frame owns (the other lanes' weights for those slots are zero).
-// VALU per frame: 2 v_pk_fma_f32 + cvt_pk + pk_max per two outputs = 81 instead of ~180; the dense part is 8F + 1..3
-// MFMAs per 16 frames with A (three non-zero rows) read from a table in LDS.
-// HALF = true (MDC_F16): the same kernel with IEEE f16 instead of bf16 operands -- and then the conv itself runs in
-// packed f16 (v_pk_fma_f16 on 32-bit registers: two filters per instruction at the plain VALU rate, ReLU = one
-// v_pk_max_f16, no conversion before the MFMA), which is what lifts the F = 10 net off the v_pk_fma_f32 bound.  f16
-// keeps 11 significant bits (bf16: 8) but only ~5 decades of range: conv outputs must stay below 65,504.
-// Numerics: conv in f32 exactly as the f32 kernel; conv outputs and dense weights rounded to bf16 (RNE), products
-// accumulated in f32 by the MFMA; bias, ReLU, softmax, first-max argmax in f32 as in deployed.hip.
+// pieces p = 4j + g (j = 0..15) of the frame's 64 pieces (row I = pieces 0..31, row Q = 32..63), read from a
+// wave-private staging area in LDS that LDS-DMA fills (every byte of the batch crosses HBM exactly once).  For each
+// piece the lane computes its 4 conv positions x F filters, applies ReLU on the packed halves, and the values ARE
+// the B operand (k order = order of production; the host lays the dense weights out to match; only classes 0..2
+// of the MFMA's 16 rows are real -- the other rows are never read back).  The sample x[w] a piece lacks for its last
+// position is the first sample of the NEXT piece: one extra ds_read_b32, zero at the row end.  Position w = 0 of
+// each row (x[-1] = 0) is an extra 2F values that only the g = 0 lane of a frame owns (the other lanes' weights for
+// those slots are zero).  The dense part is 8F + 1..3 MFMAs per 16 frames.
+//
+// HALF = false (MDC_BF16): conv in f32 with the f32 kernel's fma chain (fma(K1, x[w], fma(K0, x[w-1], b)), two
+// filters per v_pk_fma_f32), outputs rounded to bf16 (v_cvt_pk_bf16_f32 + v_pk_max_i16); dense weights bf16.
+// 2 + 2 VALU per two outputs = 81 per frame for F = 10 instead of ~180 -- but v_pk_fma_f32 is a slow instruction here.
+// HALF = true (MDC_F16): IEEE f16 operands, and then the conv itself runs in packed f16 (v_pk_fma_f16 on 32-bit
+// registers: two filters per instruction at the plain VALU rate, ReLU = one v_pk_max_f16, no conversion before the
+// MFMA), which is what lifts the F = 10 net off the v_pk_fma_f32 bound.  f16 keeps 11 significant bits (bf16: 8) but
+// only ~5 decades of range: conv outputs must stay below 65,504.
+// Both: products accumulated in f32 by the MFMA; bias, ReLU, softmax, first-max argmax in f32 as in deployed.hip.
 #include "vtcnn2_bf16_common.h"
 
 #include <algorithm>
