@@ -136,11 +136,11 @@ int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, 
  * ((byte - 127.5) * scale) with I in row 0 and Q in row 1.  Runs on the current device. */
 int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream);
 
-/* The two steps above in ONE pass for the deployed nets finalized with MDC_F32 (other kinds / dtypes: MDC_ENOTSUP,
- * use the two calls): the kernel reads
+/* The two steps above in ONE pass for the deployed nets, any of their dtypes (other kinds: MDC_ENOTSUP, use the two
+ * calls): the kernel reads
  * the raw bytes (256 B/frame instead of 1,024) and converts in registers with the arithmetic of
  * mdc_iq_u8_to_frames, so probs/labels are bit-identical to mdc_iq_u8_to_frames followed by mdc_forward.
- * iq_dev must be 8-byte aligned; probs_dev (n,3) f32 and labels_dev (n) int32 may each be NULL.  This is the
+ * iq_dev must be 16-byte aligned; probs_dev (n,3) f32 and labels_dev (n) int32 may each be NULL.  This is the
  * SDR -> classifier hand-off of the reference's README.md:5 without the frame buffer in between. */
 int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, float scale,
                       float* probs_dev, int32_t* labels_dev, void* hip_stream);

@@ -65,10 +65,15 @@ struct Bf16Geom {
 using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-template <int F, bool HALF>
+// U8 = true (mdc_forward_iq_u8): x points at raw interleaved unsigned 8-bit (I,Q) samples, 256 B per frame.  A whole
+// group is then 4 KiB (one DMA instruction = four frames), the wave's staging area holds a ring of FOUR groups
+// (three in flight while one is computed), and a lane reads the 8 bytes that hold its four samples of both rows and
+// converts the row at hand with the arithmetic of mdc_iq_u8_to_frames -- the f32 samples, and so every result, are
+// bit-identical to convert-then-forward.
+template <int F, bool HALF, bool U8>
 __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
                                                                 const float* __restrict__ wp, const uint4* __restrict__ atab,
-                                                                float* __restrict__ probs, int* __restrict__ labels) {
+                                                                float* __restrict__ probs, int* __restrict__ labels, float scale) {
     using G = Bf16Geom<F>;
     constexpr int kPhaseUnits = G::kUnits / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -110,34 +115,68 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
             glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + r * kSamples + (lane & 31) * 4, stage + r * G::kStageBytes + i * G::kPairStride);
         }
     };
+    // raw bytes: ring slot of a group = 4 DMA instructions (4 frames x 256 B each) at stage + slot * kRawGroup
+    constexpr int kRawGroup = 4 * G::kPairStride;
+    static_assert(4 * kRawGroup <= 2 * G::kStageBytes, "the ring of four raw groups fits the two row buffers");
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
+    auto stage_raw = [&](long grp, int slot) {    // groups past the end re-read the last one (constant DMA count per step)
+        const long gc = grp < ngroups ? grp : ngroups - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long fr = gc * 16 + 4 * i + (lane >> 4);
+            glds16(xb + (fr < n ? fr : n - 1) * 256 + (lane & 15) * 16, stage + slot * kRawGroup + i * G::kPairStride);
+        }
+    };
+    // raw bytes: the 8 bytes of piece 4jj + g (samples of BOTH rows) of frame f at rawmine + slot * kRawGroup + 32 jj
+    const unsigned char* rawmine = stage + (f >> 2) * G::kPairStride + (f & 3) * 256 + g * 8;
     long grp = (long)blockIdx.x * G::kWaves + wv;
-    if (grp < ngroups) stage_row(grp, 0);
-    for (; grp < ngroups; grp += gstep) {
+    if constexpr (U8) {
+        if (grp < ngroups) { stage_raw(grp, 0); stage_raw(grp + gstep, 1); stage_raw(grp + 2 * gstep, 2); }
+    } else {
+        if (grp < ngroups) stage_row(grp, 0);
+    }
+    for (int it = 0; grp < ngroups; grp += gstep, ++it) {
         const long frame = grp * 16 + f;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float x0[2] = {0.f, 0.f};      // first sample of each row (x[0], for the g = 0 lane's position w = 0)
+        const unsigned char* raw = rawmine + (it & 3) * kRawGroup;
+        if constexpr (U8) {
+            // the group three steps ahead goes into the slot whose last reader finished a step ago (lgkmcnt(0) below);
+            // then at most those three groups' twelve DMA instructions may be outstanding: this group has landed
+            stage_raw(grp + 3 * gstep, (it + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const unsigned char* mine = mine0 + r * G::kStageBytes;
-            // the row after this one goes into the other buffer now (its last reader finished a row ago, lgkmcnt(0)
-            // below); then wait until only those eight DMA instructions are outstanding: this row has landed
-            const bool more = r == 0 || grp + gstep < ngroups;
-            if (r == 0) stage_row(grp, 1);
-            else if (more) stage_row(grp + gstep, 0);
-            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!U8) {
+                // the row after this one goes into the other buffer now (its last reader finished a row ago, lgkmcnt(0)
+                // below); then wait until only those eight DMA instructions are outstanding: this row has landed
+                const bool more = r == 0 || grp + gstep < ngroups;
+                if (r == 0) stage_row(grp, 1);
+                else if (more) stage_row(grp + gstep, 0);
+                if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             // LDS reads run one unit ahead of the arithmetic: pieces, next-piece samples and the A rows of the next
             // unit are requested before this one is computed (the sched_barrier that bounds the register use would
             // otherwise put every unit's LDS latency in front of its own arithmetic)
             float4 c4n[G::kUnitPieces];
             float nbn[G::kUnitPieces];
+            uint2 r8n[G::kUnitPieces];       // raw bytes: the piece (I0 Q0 I1 Q1 | I2 Q2 I3 Q3) ...
+            unsigned nr8n[G::kUnitPieces];   // ... and the first (I, Q) pairs of the next piece
             uint4 an[G::kUnitMfma];
             auto read_unit = [&](int up) {          // up = unit within the phase
 #pragma unroll
                 for (int q = 0; q < G::kUnitPieces; ++q) {
                     const int jj = up * G::kUnitPieces + q;
-                    c4n[q] = *reinterpret_cast<const float4*>(mine + 64 * jj);
-                    nbn[q] = *reinterpret_cast<const float*>(mine + 64 * jj + 16);
+                    if constexpr (U8) {
+                        r8n[q] = *reinterpret_cast<const uint2*>(raw + 32 * jj);          // both rows live in the same 8 bytes
+                        nr8n[q] = *reinterpret_cast<const unsigned*>(raw + 32 * jj + 8);
+                    } else {
+                        c4n[q] = *reinterpret_cast<const float4*>(mine + 64 * jj);
+                        nbn[q] = *reinterpret_cast<const float*>(mine + 64 * jj + 16);
+                    }
                 }
 #pragma unroll
                 for (int mm = 0; mm < G::kUnitMfma; ++mm) an[mm] = a_mine[((r * kPhaseUnits + up) * G::kUnitMfma + mm) * 4 * kC];
@@ -150,7 +189,17 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                 float nbv[G::kUnitPieces];
                 uint4 a[G::kUnitMfma];
 #pragma unroll
-                for (int q = 0; q < G::kUnitPieces; ++q) { c4[q] = c4n[q]; nbv[q] = nbn[q]; }
+                for (int q = 0; q < G::kUnitPieces; ++q) {
+                    if constexpr (U8) {
+                        // row r = bytes r, r+2 of each dword; ((float)byte - 127.5) * scale as in iq_u8_kernel (eval_ops.hip)
+                        const unsigned d0 = r8n[q].x >> (8 * r), d1 = r8n[q].y >> (8 * r), d2 = nr8n[q] >> (8 * r);
+                        c4[q] = make_float4(((float)(d0 & 0xFFu) - 127.5f) * scale, ((float)((d0 >> 16) & 0xFFu) - 127.5f) * scale,
+                                            ((float)(d1 & 0xFFu) - 127.5f) * scale, ((float)((d1 >> 16) & 0xFFu) - 127.5f) * scale);
+                        nbv[q] = ((float)(d2 & 0xFFu) - 127.5f) * scale;
+                    } else {
+                        c4[q] = c4n[q]; nbv[q] = nbn[q];
+                    }
+                }
 #pragma unroll
                 for (int mm = 0; mm < G::kUnitMfma; ++mm) a[mm] = an[mm];
                 if (up + 1 < kPhaseUnits) read_unit(up + 1);
@@ -340,20 +389,21 @@ int deployed_bf16_pack(mdc_model* m) {
     return upload(m, 2, tab.data(), tab.size() * sizeof(unsigned short));
 }
 
-template <int F>
-static int launch_bf16(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s) {
+template <int F, bool U8>
+static int launch_bf16(const mdc_model* m, const void* x, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s) {
     using G = Bf16Geom<F>;
     const float* wp = static_cast<const float*>(m->d_pack[0]);
     const uint4* atab = static_cast<const uint4*>(m->d_pack[2]);
+    const float* xf = static_cast<const float*>(x);
     const long ngroups = (n + 15) / 16;
     long grid = (ngroups + G::kWaves - 1) / G::kWaves;
     if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 8 x 2 row buffers)
     if (m->dtype == MDC_F16) {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
-        hipLaunchKernelGGL((deployed_bf16_kernel<F, true>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, true, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
+        hipLaunchKernelGGL((deployed_bf16_kernel<F, true, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale);
     } else {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
-        hipLaunchKernelGGL((deployed_bf16_kernel<F, false>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, x, (long)n, wp, atab, probs, labels);
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, false, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
+        hipLaunchKernelGGL((deployed_bf16_kernel<F, false, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale);
     }
     MDC_HIP(hipGetLastError());
     return MDC_OK;
@@ -361,7 +411,13 @@ static int launch_bf16(const mdc_model* m, const float* x, int64_t n, float* pro
 
 int deployed_bf16_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s) {
     ProfScope ps(m, 0, s);
-    return m->topo.filters == 3 ? launch_bf16<3>(m, x, n, probs, labels, s) : launch_bf16<10>(m, x, n, probs, labels, s);
+    return m->topo.filters == 3 ? launch_bf16<3, false>(m, x, n, 0.f, probs, labels, s) : launch_bf16<10, false>(m, x, n, 0.f, probs, labels, s);
+}
+
+// raw uint8 I/Q (256 B per frame) straight into the 16-bit kernels
+int deployed_bf16_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s) {
+    ProfScope ps(m, 0, s);
+    return m->topo.filters == 3 ? launch_bf16<3, true>(m, iq, n, scale, probs, labels, s) : launch_bf16<10, true>(m, iq, n, scale, probs, labels, s);
 }
 
 }  // namespace mdc

@@ -219,15 +219,16 @@ int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, floa
         set_error("mdc_forward_iq_u8: fused raw-IQ input exists for the deployed nets only; use mdc_iq_u8_to_frames + mdc_forward");
         return MDC_ENOTSUP;
     }
-    if (m->dtype != MDC_F32) { set_error("mdc_forward_iq_u8: fused raw-IQ input exists for the f32 kernels; use mdc_iq_u8_to_frames + mdc_forward"); return MDC_ENOTSUP; }
     if (n < 0) { set_error("mdc_forward_iq_u8: negative frame count"); return MDC_EINVAL; }
     if (n == 0) return MDC_OK;
     if (!iq_dev) { set_error("mdc_forward_iq_u8: null input"); return MDC_EINVAL; }
-    if ((reinterpret_cast<uintptr_t>(iq_dev) & 7) != 0) { set_error("mdc_forward_iq_u8: input must be 8-byte aligned"); return MDC_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(iq_dev) & 15) != 0) { set_error("mdc_forward_iq_u8: input must be 16-byte aligned"); return MDC_EINVAL; }
     int cur = -1;
     MDC_HIP(hipGetDevice(&cur));
     if (cur != m->device) MDC_HIP(hipSetDevice(m->device));
-    const int rc = deployed_forward_iq_u8(m, iq_dev, n, scale, probs_dev, labels_dev, static_cast<hipStream_t>(hip_stream));
+    const int rc = (m->dtype == MDC_F32)
+                       ? deployed_forward_iq_u8(m, iq_dev, n, scale, probs_dev, labels_dev, static_cast<hipStream_t>(hip_stream))
+                       : deployed_bf16_forward_iq_u8(m, iq_dev, n, scale, probs_dev, labels_dev, static_cast<hipStream_t>(hip_stream));
     if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
     return rc;
 }

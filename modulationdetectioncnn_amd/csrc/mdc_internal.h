@@ -85,6 +85,7 @@ int deployed_pack(mdc_model* m);
 // bf16 mode (dense layer on the matrix cores, lane = frame): deployed_bf16.hip
 int deployed_bf16_pack(mdc_model* m);
 int deployed_bf16_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s);
+int deployed_bf16_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s);
 // Q6.12 integer path of the deployed nets: deployed_q612.hip
 int deployed_q612_pack(mdc_model* m);
 int deployed_q612_forward(const mdc_model* m, const void* x, int x_is_q, int64_t n, int32_t* dense, int32_t* labels, hipStream_t s);

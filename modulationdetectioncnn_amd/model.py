@@ -399,7 +399,7 @@ class VTCNN2:
         if t.numel() % 256:
             raise ValueError(f"{t.numel()} bytes is not a whole number of 256-byte frames")
         n, Cn = t.numel() // 256, self.topology.classes
-        if self.topology.kind == "deployed" and self.dtype == "f32":
+        if self.topology.kind == "deployed":
             probs = torch.empty((n, Cn), dtype=torch.float32, device=t.device)
             labels = torch.empty((n,), dtype=torch.int32, device=t.device)
             with torch.cuda.device(t.device):

@@ -259,7 +259,7 @@ def test_bf16_mode_is_independent_of_batch_composition_and_rejects_taps(dtype):
     np.testing.assert_array_equal(m.predict(x[perm]), whole[perm])
     with pytest.raises(_cabi.MdcError):
         m.predict(x[:4], tap="dense")
-    # raw bytes in bf16 mode go through the conversion pass (the fused kernel is the f32 one)
+    # raw bytes: the 16-bit kernels read them themselves; same results as converting first
     iq = np.random.default_rng(1).integers(0, 256, size=256 * 33, dtype=np.uint8)
     from modulationdetectioncnn_amd import frames_from_iq_u8
     p, _l = m.predict_iq_u8(iq, 0.02 / 127.5)

@@ -21,8 +21,10 @@ for topo in ("deployed3", "deployed10"):
     t_f32 = timed(lambda: m.forward_device(x, probs, labels))
     t_two = timed(lambda: m.forward_device(frames_from_iq_u8(iq, 0.02 / 127.5), probs, labels))
     t_fused = timed(lambda: m.predict_iq_u8(iq, 0.02 / 127.5))
-    mb = VTCNN2.synthetic(topo, seed=2016, device=0, dtype="bf16")
-    t_bf16 = timed(lambda: mb.forward_device(x, probs, labels))
-    print(f"{topo}: bf16 mode on f32 frames {n/t_bf16:.4g} frames/s")
+    for dt in ("bf16", "f16"):
+        mb = VTCNN2.synthetic(topo, seed=2016, device=0, dtype=dt)
+        t_fr = timed(lambda: mb.forward_device(x, probs, labels))
+        t_by = timed(lambda: mb.predict_iq_u8(iq, 0.02 / 127.5))
+        print(f"{topo}: {dt} mode: f32 frames {n/t_fr:.4g} frames/s | bytes, fused {n/t_by:.4g}")
     print(f"{topo}: f32 frames {n/t_f32:.4g} frames/s | bytes, two passes {n/t_two:.4g} | bytes, fused {n/t_fused:.4g} "
           f"({256*n/t_fused/1e12:.2f} TB/s of input)", flush=True)
