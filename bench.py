@@ -223,10 +223,15 @@ def run_iq_u8(filters, device, steps=20, warmup=5, n=1 << 22):
     labels = torch.empty((n,), dtype=torch.int32, device=iq.device)
     el2 = timed_region(lambda: m.forward_device(frames_from_iq_u8(iq, scale), probs=probs, labels=labels), steps, warmup,
                        sync=torch.cuda.synchronize, device=iq.device)
+    # the same bytes through the f16-mode kernel (conv in packed f16, dense on the f16 MFMA)
+    from modulationdetectioncnn_amd import VTCNN2
+    g = os.path.join(ROOT, "tests", "golden", "weights")
+    mh = VTCNN2.from_npz(os.path.join(g, "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"), device=device, dtype="f16")
+    elh = timed_region(lambda: mh.predict_iq_u8(iq, scale), steps, warmup, sync=torch.cuda.synchronize, device=iq.device)
     gbs = (256 + 16) * n * steps / el / 1e9
     return {"workload": f"deployed{filters}-iq-u8-n2^22", "value": n * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
             "dtype": "f32", "input": "uint8 interleaved I/Q, 256 B/frame, resident in HBM",
-            "two_pass_value": n * steps / el2,
+            "two_pass_value": n * steps / el2, "f16_mode_value": n * steps / elh,
             "roofline": {"bound": "hbm", "kernel": "mdc_deployed_fwd (raw-IQ form)", "achieved": gbs, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "from": "wall time, one launch per step"}}
 
