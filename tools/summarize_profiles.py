@@ -45,10 +45,10 @@ spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in th
     ("mdc_vt_head", "vt", "vt_head_kernel", 65536),
     ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3", 1 << 20),
     ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10", 1 << 20),
-    ("mdc_deployed_fwd/F3/bf16", "dep", "deployed_bf16_kernel<3, false>", 1 << 20),
-    ("mdc_deployed_fwd/F10/bf16", "dep", "deployed_bf16_kernel<10, false>", 1 << 20),
-    ("mdc_deployed_fwd/F3/f16", "dep", "deployed_bf16_kernel<3, true>", 1 << 20),
-    ("mdc_deployed_fwd/F10/f16", "dep", "deployed_bf16_kernel<10, true>", 1 << 20),
+    ("mdc_deployed_fwd/F3/bf16", "dep", "deployed_bf16_kernel<3, false, false>", 1 << 20),
+    ("mdc_deployed_fwd/F10/bf16", "dep", "deployed_bf16_kernel<10, false, false>", 1 << 20),
+    ("mdc_deployed_fwd/F3/f16", "dep", "deployed_bf16_kernel<3, true, false>", 1 << 20),
+    ("mdc_deployed_fwd/F10/f16", "dep", "deployed_bf16_kernel<10, true, false>", 1 << 20),
 ]
 out = {"note": "bytes per launch; FETCH_SIZE doubled (gfx950 wide-read correction), KiB -> bytes", "kernels": {}}
 for key, sfx, kern, frames in spec:
