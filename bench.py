@@ -269,7 +269,10 @@ def main():
     m, x, probs, labels, n, el = run_workload(name, device, args.steps, args.warmup, dist)
     total_frames = n * ngpu * args.steps
     out = {
-        "metric": "I/Q frames/sec (2x128, VT-CNN2, batch=2^20)", "value": total_frames / el, "unit": "frames/s",
+        # BASELINE.json's metric for the workloads it is quoted on; other --workload choices say what they are
+        "metric": ("I/Q frames/sec (2x128, VT-CNN2, batch=2^20)" if kind == "vtcnn2" else
+                   f"I/Q frames/sec (2x128, {'cnn.py literal model' if kind == 'cnnpy' else f'deployed {filters}-filter net'}, batch={n})"),
+        "value": total_frames / el, "unit": "frames/s",
         "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8", "f16": "f16"}[dtype],
         "data": "synthetic N(0,5e-3) f32 frames resident in HBM; " + weights,
