@@ -236,7 +236,21 @@ def run_iq_u8(filters, device, steps=20, warmup=5, n=1 << 22):
                          "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "from": "wall time, one launch per step"}}
 
 
-def main():
+def metric_name(kind, filters, n):
+    """BASELINE.json's metric string for the workloads it is quoted on (VT-CNN2 at batch 2^20); every other workload
+    or batch size says what it is."""
+    if kind == "vtcnn2":
+        return "I/Q frames/sec (2x128, VT-CNN2, batch=2^20)" if n == 1 << 20 else f"I/Q frames/sec (2x128, VT-CNN2, batch={n})"
+    what = "cnn.py literal model" if kind == "cnnpy" else f"deployed {filters}-filter net"
+    return f"I/Q frames/sec (2x128, {what}, batch={n})"
+
+
+def select_device(device):
+    import torch
+    torch.cuda.set_device(device)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -244,7 +258,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -258,7 +272,7 @@ def main():
         device = 0 if os.environ.get("MDC_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     else:
         device = 0
-    torch.cuda.set_device(device)
+    select_device(device)
     rank = dist.get_rank() if dist else 0
     ngpu = world if dist else 1
     if args.gpus != ngpu and rank == 0:
@@ -269,9 +283,7 @@ def main():
     m, x, probs, labels, n, el = run_workload(name, device, args.steps, args.warmup, dist)
     total_frames = n * ngpu * args.steps
     out = {
-        # BASELINE.json's metric for the workloads it is quoted on; other --workload choices say what they are
-        "metric": ("I/Q frames/sec (2x128, VT-CNN2, batch=2^20)" if kind == "vtcnn2" else
-                   f"I/Q frames/sec (2x128, {'cnn.py literal model' if kind == 'cnnpy' else f'deployed {filters}-filter net'}, batch={n})"),
+        "metric": metric_name(kind, filters, n),
         "value": total_frames / el, "unit": "frames/s",
         "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8", "f16": "f16"}[dtype],

@@ -17,7 +17,11 @@
  * nothing throws across the boundary.  All device buffers belong to the caller; the
  * library owns only the packed weights.  mdc_forward is asynchronous on the caller's HIP
  * stream and performs no device synchronisation.  A finalized model is immutable and
- * mdc_forward on it is re-entrant (one model per device; any number of streams).
+ * mdc_forward on it is re-entrant (one model per device; any number of streams and host threads; with
+ * mdc_set_profiling on, the per-launch event lists are kept under a mutex, so that stays true).  Every entry point
+ * that touches a device selects the model's device for the duration of the call and restores the caller's.
+ * The library is built with C++ exceptions enabled internally: an allocation failure inside it (weight copies,
+ * packing buffers, event lists) is caught at the boundary and returned as MDC_ENOMEM.
  */
 #ifndef MDC_H
 #define MDC_H
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MDC_ABI_VERSION 1
+#define MDC_ABI_VERSION 2   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows */
 
 /* error codes (negative errno values) */
 #define MDC_OK        0
@@ -131,24 +135,43 @@ int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64
 int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, int classes,
                   int64_t* counts_dev, int64_t* bad_dev, void* hip_stream);
 
+/* The per-SNR evaluation loop of cnn.py:228-259 in ONE launch: bin_dev[i] in [0,bins) says which SNR (or any other
+ * grouping) frame i belongs to, and counts_dev[(b*classes + t)*classes + p] += 1 -- a (bins, classes, classes) int64
+ * histogram, caller-zeroed; acc[b] = trace / sum of slice b (cnn.py:257-259).  Entries with a label or bin out of
+ * range go to *bad_dev (may be NULL).  classes <= 32, bins <= 65536.  Runs on the current device. */
+int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, const int32_t* bin_dev, int64_t n,
+                         int classes, int bins, int64_t* counts_dev, int64_t* bad_dev, void* hip_stream);
+
 /* Raw SDR bytes -> frames: iq_dev holds n frames of 128 interleaved unsigned 8-bit (I,Q) pairs (256 B/frame, the
  * RTL-SDR format of the front-end in the reference's README.md:5); x_dev (n,2,128) f32 receives
  * ((byte - 127.5) * scale) with I in row 0 and Q in row 1.  Runs on the current device. */
 int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream);
 
-/* The two steps above in ONE pass for the deployed nets, any of their dtypes (other kinds: MDC_ENOTSUP, use the two
- * calls): the kernel reads
- * the raw bytes (256 B/frame instead of 1,024) and converts in registers with the arithmetic of
- * mdc_iq_u8_to_frames, so probs/labels are bit-identical to mdc_iq_u8_to_frames followed by mdc_forward.
- * iq_dev must be 16-byte aligned; probs_dev (n,3) f32 and labels_dev (n) int32 may each be NULL.  This is the
- * SDR -> classifier hand-off of the reference's README.md:5 without the frame buffer in between. */
-int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, float scale,
-                      float* probs_dev, int32_t* labels_dev, void* hip_stream);
+/* Sliding windows over one contiguous capture (the live RTL-SDR stream of README.md:5): window i holds the 128 (I,Q)
+ * pairs starting at pair i*hop, i.e. bytes [2*hop*i, 2*hop*i + 256) of iq_dev, which must hold 2*hop*(n-1) + 256 bytes.
+ * hop = MDC_HOP_FRAME (128) is mdc_iq_u8_to_frames.  x_dev (n,2,128) f32.  Runs on the current device. */
+#define MDC_HOP_FRAME 128
+int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale, float* x_dev, void* hip_stream);
+
+/* Conversion and forward in ONE pass, for the deployed nets (any of their dtypes) and the VT-CNN2 family (f32, bf16,
+ * fp8): the forward kernel itself reads the raw bytes (the deployed kernels' loads / LDS-DMA, the VT-CNN2 conv
+ * kernels' frame staging) and converts in registers with the arithmetic of mdc_iq_u8_to_frames, so probs/labels are
+ * bit-identical to mdc_iq_u8_windows followed by mdc_forward -- with 2*hop (<= 256) instead of 1,024 B of HBM input
+ * per window and no frame buffer in between.  n windows, `hop` pairs apart as in mdc_iq_u8_windows (MDC_HOP_FRAME:
+ * disjoint 256-byte frames); iq_dev 2-byte aligned (windows at odd hops are not better aligned than that anyway: the
+ * kernels use gfx950's unaligned global loads), 2*hop*(n-1) + 256 bytes.  probs_dev (n,C) f32 and labels_dev (n)
+ * int32 may each be NULL.  workspace: as mdc_forward (mdc_workspace_bytes(m, n); NULL/0 for the deployed nets).
+ * MDC_KIND_CNNPY: MDC_ENOTSUP (use the two calls).  This is the SDR -> classifier hand-off of README.md:5. */
+int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, int64_t hop, float scale,
+                      float* probs_dev, int32_t* labels_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
 /* Measurement support (bench.py roofline leg): when on, mdc_forward brackets each kernel
  * launch with HIP events on the launch stream; mdc_profile_read synchronises on them and
  * returns the summed device time and launch count of kernel slot `slot` since the last
- * mdc_profile_reset.  Off by default; never on in the timed region of the headline number. */
+ * mdc_profile_reset.  Off by default; never on in the timed region of the headline number.
+ * Forwards may run concurrently with profiling on (the event lists are mutex-guarded); mdc_set_profiling /
+ * mdc_profile_reset themselves must not race with forwards of the same model. */
 int mdc_set_profiling(mdc_model* m, int on);
 int mdc_profile_slots(const mdc_model* m);
 const char* mdc_profile_name(const mdc_model* m, int slot);

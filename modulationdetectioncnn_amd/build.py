@@ -2,10 +2,13 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so
 travels to the GPU box with the repo snapshot.  Objects are cached per source by
-mtime so rebuilding after touching one kernel file takes seconds.
+mtime AND by the exact flag set (a stamp file records the flags of the last build: a build
+with other flags, e.g. a -DMDC_ABLATIONS probe build, never leaves its objects for a plain
+build to pick up), so rebuilding after touching one kernel file takes seconds.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -20,7 +23,9 @@ LIB = os.path.join(HERE, "libmdc.so")
 ARCH = "gfx950"
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"),
-            "-I", CSRC, "-Wall", "-Wno-unused-function", "-fno-exceptions"]
+            "-I", CSRC, "-Wall", "-Wno-unused-function"]
+# (no -fno-exceptions: the C ABI catches std::bad_alloc & co. at the boundary and returns MDC_ENOMEM, mdc_api.hip)
+STAMP = os.path.join(OBJ, "flags.stamp")
 
 
 def _hipcc() -> str:
@@ -45,6 +50,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "mdc.h")]
+    flag_key = hashlib.sha256(" ".join([*CXXFLAGS, *extra_flags]).encode()).hexdigest()
+    if not (os.path.exists(STAMP) and open(STAMP).read().strip() == flag_key):
+        force = True        # objects (if any) were built with other flags
     jobs = []
     objs = []
     for src in sources():
@@ -66,8 +74,12 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         return obj
 
     if jobs:
+        if os.path.exists(STAMP):
+            os.remove(STAMP)        # a build interrupted half way must not look complete
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(cc, jobs))
+    with open(STAMP, "w") as f:
+        f.write(flag_key + "\n")
     if jobs or not _newer(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -169,12 +169,14 @@ __device__ __forceinline__ float rows_sum(float m) {       // sum over the four 
 // U8 = true: x points at raw interleaved unsigned 8-bit (I,Q) samples (256 B per frame, mdc_forward_iq_u8); a lane
 // loads the 8 bytes that hold its four samples of BOTH rows (lanes l and l+32 read the same address) and converts
 // the row it owns with the arithmetic of iq_u8_kernel (eval_ops.hip), so the results are bit-identical to
-// mdc_iq_u8_to_frames followed by mdc_forward -- with 256 instead of 1,024 B of HBM input per frame.
+// mdc_iq_u8_to_frames followed by mdc_forward -- with 256 instead of 1,024 B of HBM input per frame.  Window f of the
+// capture starts at byte f * hop2 (hop2 = 256: disjoint frames; smaller: overlapping windows of a live stream, whose
+// bytes are then fetched from HBM once and re-read from cache); only 2-byte alignment of a window is assumed.
 template <int F, int TAP, int ABL = 0, bool TAIL = false, bool U8 = false>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
 __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restrict__ x, long n,
                                                            const float* __restrict__ wp,
                                                            float* __restrict__ probs, int* __restrict__ labels,
-                                                           float* __restrict__ tap_dense, float scale = 0.f) {
+                                                           float* __restrict__ tap_dense, float scale = 0.f, long hop2 = 256) {
     const int lane = threadIdx.x & 63;
     const int lp = lane & 31;
     using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
         // frames stream by, read once per block by the lane that finishes the frame): no extra HBM/L2 reads
         float eI = 0.f, eQ = 0.f;
         const float4* px = reinterpret_cast<const float4*>(x + base * kFrameFloats) + lane;
-        const uint2* pb = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(x) + base * 256) + lp;
+        const unsigned char* pb = reinterpret_cast<const unsigned char*>(x) + base * hop2 + lp * 8;
         using Raw = typename std::conditional<U8, uint2, float4>::type;
         Raw cur_raw[4], nx[4];
         float4 cur[4];
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
             if constexpr (U8) {
                 // past the end of a ragged block: bytes whose conversion is not used (those frames are never stored)
                 if (TAIL && j >= n) return make_uint2(0u, 0u);
-                return pb[(long)j * 32];
+                return load8_unaligned(pb + (long)j * hop2);
             } else {
                 if (!TAIL) return px[(long)j * 64];
                 return (j < n) ? px[(long)j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -457,25 +459,26 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
 
 // Raw SDR bytes straight into the deployed nets: full 64-frame blocks by the fast kernel,
 // a ragged tail by its TAIL form; no frame buffer in between.
-int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s) {
+int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int64_t hop, float scale, float* probs, int32_t* labels, hipStream_t s) {
     const float* wp = static_cast<const float*>(m->d_pack[0]);
     const int F = m->topo.filters;
     const long nfull = (n / 64) * 64;
+    const long hop2 = 2 * (long)hop;
     const float* xb = reinterpret_cast<const float*>(iq);
     ProfScope ps(m, 0, s);
     if (nfull > 0) {
         long grid = (nfull / 64 + 3) / 4;
         if (grid > 2048) grid = 2048;
-        if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale);
-        else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale);
+        if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale, hop2);
+        else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale, hop2);
     }
     if (nfull < n) {
         const long nt = n - nfull;
-        const float* xt = reinterpret_cast<const float*>(iq + nfull * 256);
+        const float* xt = reinterpret_cast<const float*>(iq + nfull * hop2);
         float* pt = probs ? probs + nfull * 3 : nullptr;
         int* lt = labels ? labels + nfull : nullptr;
-        if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale);
-        else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale);
+        if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale, hop2);
+        else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale, hop2);
     }
     MDC_HIP(hipGetLastError());
     return MDC_OK;

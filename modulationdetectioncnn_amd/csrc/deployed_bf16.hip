@@ -73,7 +73,7 @@ using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
 template <int F, bool HALF, bool U8>
 __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
                                                                 const float* __restrict__ wp, const uint4* __restrict__ atab,
-                                                                float* __restrict__ probs, int* __restrict__ labels, float scale) {
+                                                                float* __restrict__ probs, int* __restrict__ labels, float scale, long hop2) {
     using G = Bf16Geom<F>;
     constexpr int kPhaseUnits = G::kUnits / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long fr = gc * 16 + 4 * i + (lane >> 4);
-            glds16(xb + (fr < n ? fr : n - 1) * 256 + (lane & 15) * 16, stage + slot * kRawGroup + i * G::kPairStride);
+            glds16(xb + (fr < n ? fr : n - 1) * hop2 + (lane & 15) * 16, stage + slot * kRawGroup + i * G::kPairStride);
         }
     };
     // raw bytes: the 8 bytes of piece 4jj + g (samples of BOTH rows) of frame f at rawmine + slot * kRawGroup + 32 jj
@@ -390,7 +390,7 @@ int deployed_bf16_pack(mdc_model* m) {
 }
 
 template <int F, bool U8>
-static int launch_bf16(const mdc_model* m, const void* x, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s) {
+static int launch_bf16(const mdc_model* m, const void* x, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s, long hop2 = 256) {
     using G = Bf16Geom<F>;
     const float* wp = static_cast<const float*>(m->d_pack[0]);
     const uint4* atab = static_cast<const uint4*>(m->d_pack[2]);
@@ -400,10 +400,10 @@ static int launch_bf16(const mdc_model* m, const void* x, int64_t n, float scale
     if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 8 x 2 row buffers)
     if (m->dtype == MDC_F16) {
         MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, true, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
-        hipLaunchKernelGGL((deployed_bf16_kernel<F, true, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale);
+        hipLaunchKernelGGL((deployed_bf16_kernel<F, true, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale, hop2);
     } else {
         MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, false, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
-        hipLaunchKernelGGL((deployed_bf16_kernel<F, false, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale);
+        hipLaunchKernelGGL((deployed_bf16_kernel<F, false, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale, hop2);
     }
     MDC_HIP(hipGetLastError());
     return MDC_OK;
@@ -415,9 +415,10 @@ int deployed_bf16_forward(const mdc_model* m, const float* x, int64_t n, float* 
 }
 
 // raw uint8 I/Q (256 B per frame) straight into the 16-bit kernels
-int deployed_bf16_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s) {
+int deployed_bf16_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int64_t hop, float scale, float* probs, int32_t* labels, hipStream_t s) {
     ProfScope ps(m, 0, s);
-    return m->topo.filters == 3 ? launch_bf16<3, true>(m, iq, n, scale, probs, labels, s) : launch_bf16<10, true>(m, iq, n, scale, probs, labels, s);
+    const long hop2 = 2 * (long)hop;
+    return m->topo.filters == 3 ? launch_bf16<3, true>(m, iq, n, scale, probs, labels, s, hop2) : launch_bf16<10, true>(m, iq, n, scale, probs, labels, s, hop2);
 }
 
 }  // namespace mdc

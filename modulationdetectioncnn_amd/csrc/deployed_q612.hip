@@ -26,7 +26,9 @@ constexpr int kMaxClasses = 8;
 
 __device__ __forceinline__ int wrap18(int v) { return (v << 14) >> 14; }
 __device__ __forceinline__ int select18(long long m) {          // {m[35], m[28:12]} as a signed 18-bit value
-    return (int)((m >> 12) & 0x1FFFF) - ((m < 0) ? (1 << 17) : 0);
+    // mult_out is a 36-bit wire (sv:650, 671): the sign is BIT 35 of the sum, not the sign of the unwrapped value --
+    // they differ exactly when a*b + c*d = +2^35 (all four operands -2^17), which wraps to -2^35
+    return (int)((m >> 12) & 0x1FFFF) - (int)(((m >> 35) & 1) << 17);
 }
 __device__ __forceinline__ int quant(float v) {                  // float2fix: truncate toward zero, wrap to 18 bits
     return wrap18((int)truncf(v * 4096.f));

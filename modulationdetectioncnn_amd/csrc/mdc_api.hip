@@ -3,6 +3,8 @@
 #include "mdc_internal.h"
 
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <new>
 
 namespace mdc {
@@ -29,30 +31,58 @@ int upload(mdc_model* m, int idx, const void* host, size_t bytes) {
 
 ProfScope::ProfScope(const mdc_model* mm, int slot_, hipStream_t s_) : m(const_cast<mdc_model*>(mm)), slot(slot_), s(s_) {
     if (!m->profiling) return;
-    hipEvent_t e;
-    if (hipEventCreate(&e) == hipSuccess) {
-        (void)hipEventRecord(e, s);
-        m->slots[slot].ev.push_back(e);
-    }
+    if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
+    (void)hipEventRecord(start, s);
 }
 ProfScope::~ProfScope() {
-    if (!m->profiling) return;
-    if (m->slots[slot].ev.size() % 2 == 1) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) == hipSuccess) {
-            (void)hipEventRecord(e, s);
-            m->slots[slot].ev.push_back(e);
-        } else {
-            hipEvent_t b = m->slots[slot].ev.back();
-            (void)hipEventDestroy(b);
-            m->slots[slot].ev.pop_back();
-        }
+    if (!start) return;
+    hipEvent_t stop = nullptr;
+    if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start); return; }
+    (void)hipEventRecord(stop, s);
+    try {
+        std::lock_guard<std::mutex> g(m->prof_mu);
+        std::vector<hipEvent_t>& ev = m->slots[slot].ev;
+        ev.reserve(ev.size() + 2);      // both or neither
+        ev.push_back(start);
+        ev.push_back(stop);
+    } catch (...) {                     // out of host memory: drop the sample, never the process
+        (void)hipEventDestroy(start);
+        (void)hipEventDestroy(stop);
     }
 }
+
+// Device guard: the entry points run on the model's device and leave the caller's current device as they found it.
+struct DeviceScope {
+    int prev = -1, want;
+    bool ok = true;
+    explicit DeviceScope(int device) : want(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
+    }
+    ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
 
 }  // namespace mdc
 
 using namespace mdc;
+
+// Nothing throws across the boundary: the library is built WITH exceptions so that an allocation failure inside
+// (std::vector growth in the packers, event lists) surfaces as MDC_ENOMEM instead of aborting the host process.
+template <class Fn>
+static int guarded(const char* what, Fn&& fn) noexcept {
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory", what);
+        return MDC_ENOMEM;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", what, e.what());
+        return MDC_EIO;
+    } catch (...) {
+        set_error("%s: unexpected exception", what);
+        return MDC_EIO;
+    }
+}
 
 static int layer_layout(mdc_model* m) {
     const mdc_topology& t = m->topo;
@@ -98,26 +128,29 @@ int mdc_abi_version(void) { return MDC_ABI_VERSION; }
 const char* mdc_last_error(void) { return g_err; }
 
 int mdc_create(const mdc_topology* topo, int device, mdc_model** out) {
-    if (!topo || !out) { set_error("mdc_create: null argument"); return MDC_EINVAL; }
-    *out = nullptr;
-    for (int r : topo->reserved) if (r != 0) { set_error("mdc_create: reserved fields must be 0"); return MDC_EINVAL; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MDC_ENODEV; }
-    if (device < 0 || device >= ndev) { set_error("device %d out of range (have %d)", device, ndev); return MDC_ENODEV; }
-    hipDeviceProp_t prop;
-    MDC_HIP(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        set_error("device %d is %s; libmdc.so carries gfx950 (MI355X) code only", device, prop.gcnArchName);
-        return MDC_ENODEV;
-    }
-    mdc_model* m = new (std::nothrow) mdc_model();
-    if (!m) { set_error("out of host memory"); return MDC_ENOMEM; }
-    m->topo = *topo;
-    m->device = device;
-    int rc = layer_layout(m);
-    if (rc != MDC_OK) { delete m; return rc; }
-    *out = m;
-    return MDC_OK;
+    return guarded("mdc_create", [&]() -> int {
+        if (!topo || !out) { set_error("mdc_create: null argument"); return MDC_EINVAL; }
+        *out = nullptr;
+        for (int r : topo->reserved) if (r != 0) { set_error("mdc_create: reserved fields must be 0"); return MDC_EINVAL; }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MDC_ENODEV; }
+        if (device < 0 || device >= ndev) { set_error("device %d out of range (have %d)", device, ndev); return MDC_ENODEV; }
+        hipDeviceProp_t prop;
+        MDC_HIP(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            set_error("device %d is %s; libmdc.so carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+            return MDC_ENODEV;
+        }
+        mdc_model* m = new (std::nothrow) mdc_model();
+        if (!m) { set_error("out of host memory"); return MDC_ENOMEM; }
+        m->topo = *topo;
+        m->device = device;
+        int rc = MDC_ENOMEM;
+        try { rc = layer_layout(m); } catch (...) { delete m; throw; }
+        if (rc != MDC_OK) { delete m; return rc; }
+        *out = m;
+        return MDC_OK;
+    });
 }
 
 int mdc_num_layers(const mdc_model* m) {
@@ -134,49 +167,55 @@ int mdc_layer_sizes(const mdc_model* m, int layer, size_t* kernel_elems, size_t*
 
 int mdc_set_weights(mdc_model* m, int layer, const float* kernel_host, size_t kernel_elems,
                     const float* bias_host, size_t bias_elems) {
-    if (!m || !kernel_host || !bias_host) { set_error("mdc_set_weights: null argument"); return MDC_EINVAL; }
-    if (m->finalized) { set_error("mdc_set_weights: model is finalized (immutable)"); return MDC_ESTATE; }
-    if (layer < 0 || layer >= m->nlayers) { set_error("mdc_set_weights: layer %d out of range 0..%d", layer, m->nlayers - 1); return MDC_EINVAL; }
-    if (kernel_elems != m->nk[layer] || bias_elems != m->nb[layer]) {
-        set_error("mdc_set_weights: layer %d expects kernel %zu / bias %zu elements, got %zu / %zu",
-                  layer, m->nk[layer], m->nb[layer], kernel_elems, bias_elems);
-        return MDC_EINVAL;
-    }
-    m->hk[layer].assign(kernel_host, kernel_host + kernel_elems);
-    m->hb[layer].assign(bias_host, bias_host + bias_elems);
-    m->have[layer] = true;
-    return MDC_OK;
+    return guarded("mdc_set_weights", [&]() -> int {
+        if (!m || !kernel_host || !bias_host) { set_error("mdc_set_weights: null argument"); return MDC_EINVAL; }
+        if (m->finalized) { set_error("mdc_set_weights: model is finalized (immutable)"); return MDC_ESTATE; }
+        if (layer < 0 || layer >= m->nlayers) { set_error("mdc_set_weights: layer %d out of range 0..%d", layer, m->nlayers - 1); return MDC_EINVAL; }
+        if (kernel_elems != m->nk[layer] || bias_elems != m->nb[layer]) {
+            set_error("mdc_set_weights: layer %d expects kernel %zu / bias %zu elements, got %zu / %zu",
+                      layer, m->nk[layer], m->nb[layer], kernel_elems, bias_elems);
+            return MDC_EINVAL;
+        }
+        m->have[layer] = false;
+        m->hk[layer].assign(kernel_host, kernel_host + kernel_elems);      // may throw bad_alloc -> MDC_ENOMEM
+        m->hb[layer].assign(bias_host, bias_host + bias_elems);
+        m->have[layer] = true;
+        return MDC_OK;
+    });
 }
 
 int mdc_finalize(mdc_model* m, int dtype) {
-    if (!m) { set_error("null model"); return MDC_EINVAL; }
-    if (m->finalized) { set_error("mdc_finalize: already finalized"); return MDC_ESTATE; }
-    for (int l = 0; l < m->nlayers; ++l)
-        if (!m->have[l]) { set_error("mdc_finalize: layer %d has no weights", l); return MDC_ESTATE; }
-    if (dtype != MDC_F32 && dtype != MDC_BF16 && dtype != MDC_FP8 && dtype != MDC_F16) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
-    if (dtype == MDC_F16 && m->topo.kind != MDC_KIND_DEPLOYED) { set_error("f16 is implemented for the deployed nets only"); return MDC_ENOTSUP; }
-    if (dtype == MDC_FP8 && m->topo.kind != MDC_KIND_VTCNN2) { set_error("fp8 is implemented for the vtcnn2 family only"); return MDC_ENOTSUP; }
-    if (dtype == MDC_BF16 && m->topo.kind == MDC_KIND_CNNPY) { set_error("bf16 is implemented for the vtcnn2 and deployed families only"); return MDC_ENOTSUP; }
-    m->dtype = dtype;
-    MDC_HIP(hipSetDevice(m->device));
-    int rc;
-    switch (m->topo.kind) {
-        case MDC_KIND_DEPLOYED:
-            rc = deployed_pack(m);
-            if (rc == MDC_OK) rc = deployed_q612_pack(m);
-            if (rc == MDC_OK && (dtype == MDC_BF16 || dtype == MDC_F16)) rc = deployed_bf16_pack(m);
-            break;
-        case MDC_KIND_VTCNN2:   rc = vtcnn2_pack(m); break;
-        case MDC_KIND_CNNPY:    rc = cnnpy_pack(m); break;
-        default: rc = MDC_EINVAL;
-    }
-    if (rc != MDC_OK) return rc;
-    for (int l = 0; l < m->nlayers; ++l) {   // host copies no longer needed
-        std::vector<float>().swap(m->hk[l]);
-        std::vector<float>().swap(m->hb[l]);
-    }
-    m->finalized = true;
-    return MDC_OK;
+    return guarded("mdc_finalize", [&]() -> int {
+        if (!m) { set_error("null model"); return MDC_EINVAL; }
+        if (m->finalized) { set_error("mdc_finalize: already finalized"); return MDC_ESTATE; }
+        for (int l = 0; l < m->nlayers; ++l)
+            if (!m->have[l]) { set_error("mdc_finalize: layer %d has no weights", l); return MDC_ESTATE; }
+        if (dtype != MDC_F32 && dtype != MDC_BF16 && dtype != MDC_FP8 && dtype != MDC_F16) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
+        if (dtype == MDC_F16 && m->topo.kind != MDC_KIND_DEPLOYED) { set_error("f16 is implemented for the deployed nets only"); return MDC_ENOTSUP; }
+        if (dtype == MDC_FP8 && m->topo.kind != MDC_KIND_VTCNN2) { set_error("fp8 is implemented for the vtcnn2 family only"); return MDC_ENOTSUP; }
+        if (dtype == MDC_BF16 && m->topo.kind == MDC_KIND_CNNPY) { set_error("bf16 is implemented for the vtcnn2 and deployed families only"); return MDC_ENOTSUP; }
+        m->dtype = dtype;
+        DeviceScope dev(m->device);      // uploads go to the model's device; the caller's current device is restored
+        if (!dev.ok) { set_error("mdc_finalize: cannot select device %d", m->device); return MDC_EIO; }
+        int rc;
+        switch (m->topo.kind) {
+            case MDC_KIND_DEPLOYED:
+                rc = deployed_pack(m);
+                if (rc == MDC_OK) rc = deployed_q612_pack(m);
+                if (rc == MDC_OK && (dtype == MDC_BF16 || dtype == MDC_F16)) rc = deployed_bf16_pack(m);
+                break;
+            case MDC_KIND_VTCNN2:   rc = vtcnn2_pack(m); break;
+            case MDC_KIND_CNNPY:    rc = cnnpy_pack(m); break;
+            default: rc = MDC_EINVAL;
+        }
+        if (rc != MDC_OK) return rc;
+        for (int l = 0; l < m->nlayers; ++l) {   // host copies no longer needed
+            std::vector<float>().swap(m->hk[l]);
+            std::vector<float>().swap(m->hb[l]);
+        }
+        m->finalized = true;
+        return MDC_OK;
+    });
 }
 
 size_t mdc_workspace_bytes(const mdc_model* m, int64_t n) {
@@ -187,50 +226,50 @@ size_t mdc_workspace_bytes(const mdc_model* m, int64_t n) {
 
 int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n, float* probs_dev, int32_t* labels_dev,
                 float* tap_dev, int tap, void* workspace_dev, size_t workspace_bytes, void* hip_stream) {
-    if (!m) { set_error("null model"); return MDC_EINVAL; }
-    if (!m->finalized) { set_error("mdc_forward: model not finalized"); return MDC_ESTATE; }
-    if (n < 0) { set_error("mdc_forward: negative frame count"); return MDC_EINVAL; }
-    if (n == 0) return MDC_OK;
-    if (!x_dev) { set_error("mdc_forward: null input"); return MDC_EINVAL; }
-    if ((reinterpret_cast<uintptr_t>(x_dev) & 15) != 0) { set_error("mdc_forward: input must be 16-byte aligned"); return MDC_EINVAL; }
-    if (tap < MDC_TAP_NONE || tap > MDC_TAP_HIDDEN) { set_error("mdc_forward: bad tap %d", tap); return MDC_EINVAL; }
-    if ((tap != MDC_TAP_NONE) != (tap_dev != nullptr)) { set_error("mdc_forward: tap and tap_dev must be given together"); return MDC_EINVAL; }
-    int cur = -1;
-    MDC_HIP(hipGetDevice(&cur));
-    if (cur != m->device) MDC_HIP(hipSetDevice(m->device));
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const float* x = static_cast<const float*>(x_dev);
-    int rc;
-    switch (m->topo.kind) {
-        case MDC_KIND_DEPLOYED: rc = deployed_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, s); break;
-        case MDC_KIND_VTCNN2:   rc = vtcnn2_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, workspace_dev, workspace_bytes, s); break;
-        case MDC_KIND_CNNPY:    rc = cnnpy_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, s); break;
-        default: rc = MDC_EINVAL;
-    }
-    if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
-    return rc;
+    return guarded("mdc_forward", [&]() -> int {
+        if (!m) { set_error("null model"); return MDC_EINVAL; }
+        if (!m->finalized) { set_error("mdc_forward: model not finalized"); return MDC_ESTATE; }
+        if (n < 0) { set_error("mdc_forward: negative frame count"); return MDC_EINVAL; }
+        if (n == 0) return MDC_OK;
+        if (!x_dev) { set_error("mdc_forward: null input"); return MDC_EINVAL; }
+        if ((reinterpret_cast<uintptr_t>(x_dev) & 15) != 0) { set_error("mdc_forward: input must be 16-byte aligned"); return MDC_EINVAL; }
+        if (tap < MDC_TAP_NONE || tap > MDC_TAP_HIDDEN) { set_error("mdc_forward: bad tap %d", tap); return MDC_EINVAL; }
+        if ((tap != MDC_TAP_NONE) != (tap_dev != nullptr)) { set_error("mdc_forward: tap and tap_dev must be given together"); return MDC_EINVAL; }
+        DeviceScope dev(m->device);
+        if (!dev.ok) { set_error("mdc_forward: cannot select device %d", m->device); return MDC_EIO; }
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        const float* x = static_cast<const float*>(x_dev);
+        switch (m->topo.kind) {
+            case MDC_KIND_DEPLOYED: return deployed_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, s);
+            case MDC_KIND_VTCNN2:   return vtcnn2_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, workspace_dev, workspace_bytes, s);
+            case MDC_KIND_CNNPY:    return cnnpy_forward(m, x, n, probs_dev, labels_dev, tap_dev, tap, s);
+            default: return MDC_EINVAL;
+        }
+    });
 }
 
-int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, float scale, float* probs_dev, int32_t* labels_dev,
-                      void* hip_stream) {
-    if (!m) { set_error("null model"); return MDC_EINVAL; }
-    if (!m->finalized) { set_error("mdc_forward_iq_u8: model not finalized"); return MDC_ESTATE; }
-    if (m->topo.kind != MDC_KIND_DEPLOYED) {
-        set_error("mdc_forward_iq_u8: fused raw-IQ input exists for the deployed nets only; use mdc_iq_u8_to_frames + mdc_forward");
-        return MDC_ENOTSUP;
-    }
-    if (n < 0) { set_error("mdc_forward_iq_u8: negative frame count"); return MDC_EINVAL; }
-    if (n == 0) return MDC_OK;
-    if (!iq_dev) { set_error("mdc_forward_iq_u8: null input"); return MDC_EINVAL; }
-    if ((reinterpret_cast<uintptr_t>(iq_dev) & 15) != 0) { set_error("mdc_forward_iq_u8: input must be 16-byte aligned"); return MDC_EINVAL; }
-    int cur = -1;
-    MDC_HIP(hipGetDevice(&cur));
-    if (cur != m->device) MDC_HIP(hipSetDevice(m->device));
-    const int rc = (m->dtype == MDC_F32)
-                       ? deployed_forward_iq_u8(m, iq_dev, n, scale, probs_dev, labels_dev, static_cast<hipStream_t>(hip_stream))
-                       : deployed_bf16_forward_iq_u8(m, iq_dev, n, scale, probs_dev, labels_dev, static_cast<hipStream_t>(hip_stream));
-    if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
-    return rc;
+int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, int64_t hop, float scale,
+                      float* probs_dev, int32_t* labels_dev, void* workspace_dev, size_t workspace_bytes, void* hip_stream) {
+    return guarded("mdc_forward_iq_u8", [&]() -> int {
+        if (!m) { set_error("null model"); return MDC_EINVAL; }
+        if (!m->finalized) { set_error("mdc_forward_iq_u8: model not finalized"); return MDC_ESTATE; }
+        if (m->topo.kind == MDC_KIND_CNNPY) {
+            set_error("mdc_forward_iq_u8: raw-IQ input exists for the deployed and vtcnn2 families; use mdc_iq_u8_to_frames + mdc_forward");
+            return MDC_ENOTSUP;
+        }
+        if (n < 0) { set_error("mdc_forward_iq_u8: negative window count"); return MDC_EINVAL; }
+        if (hop < 1 || hop > (int64_t)1 << 24) { set_error("mdc_forward_iq_u8: hop must be in 1..2^24 sample pairs (got %lld)", (long long)hop); return MDC_EINVAL; }
+        if (n == 0) return MDC_OK;
+        if (!iq_dev) { set_error("mdc_forward_iq_u8: null input"); return MDC_EINVAL; }
+        if ((reinterpret_cast<uintptr_t>(iq_dev) & 1) != 0) { set_error("mdc_forward_iq_u8: input must start on a whole (I,Q) pair (2-byte aligned)"); return MDC_EINVAL; }
+        DeviceScope dev(m->device);
+        if (!dev.ok) { set_error("mdc_forward_iq_u8: cannot select device %d", m->device); return MDC_EIO; }
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        if (m->topo.kind == MDC_KIND_VTCNN2)
+            return vtcnn2_forward_iq_u8(m, iq_dev, n, hop, scale, probs_dev, labels_dev, workspace_dev, workspace_bytes, s);
+        return (m->dtype == MDC_F32) ? deployed_forward_iq_u8(m, iq_dev, n, hop, scale, probs_dev, labels_dev, s)
+                                     : deployed_bf16_forward_iq_u8(m, iq_dev, n, hop, scale, probs_dev, labels_dev, s);
+    });
 }
 
 int mdc_set_fp8_input_absmax(mdc_model* m, float absmax) {
@@ -243,18 +282,18 @@ int mdc_set_fp8_input_absmax(mdc_model* m, float absmax) {
 
 int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64_t n, int32_t* dense_dev, int32_t* labels_dev,
                      void* hip_stream) {
-    if (!m) { set_error("null model"); return MDC_EINVAL; }
-    if (!m->finalized) { set_error("mdc_forward_q612: model not finalized"); return MDC_ESTATE; }
-    if (m->topo.kind != MDC_KIND_DEPLOYED) { set_error("mdc_forward_q612: the FPGA datapath exists for the deployed nets only"); return MDC_ENOTSUP; }
-    if (n < 0) { set_error("mdc_forward_q612: negative frame count"); return MDC_EINVAL; }
-    if (n == 0) return MDC_OK;
-    if (!x_dev) { set_error("mdc_forward_q612: null input"); return MDC_EINVAL; }
-    int cur = -1;
-    MDC_HIP(hipGetDevice(&cur));
-    if (cur != m->device) MDC_HIP(hipSetDevice(m->device));
-    const int rc = deployed_q612_forward(m, x_dev, x_is_q612 != 0, n, dense_dev, labels_dev, static_cast<hipStream_t>(hip_stream));
-    if (cur != m->device && cur >= 0) (void)hipSetDevice(cur);
-    return rc;
+    return guarded("mdc_forward_q612", [&]() -> int {
+        if (!m) { set_error("null model"); return MDC_EINVAL; }
+        if (!m->finalized) { set_error("mdc_forward_q612: model not finalized"); return MDC_ESTATE; }
+        if (m->topo.kind != MDC_KIND_DEPLOYED) { set_error("mdc_forward_q612: the FPGA datapath exists for the deployed nets only"); return MDC_ENOTSUP; }
+        if (n < 0) { set_error("mdc_forward_q612: negative frame count"); return MDC_EINVAL; }
+        if (n == 0) return MDC_OK;
+        if (!x_dev) { set_error("mdc_forward_q612: null input"); return MDC_EINVAL; }
+        if ((reinterpret_cast<uintptr_t>(x_dev) & 15) != 0) { set_error("mdc_forward_q612: input must be 16-byte aligned"); return MDC_EINVAL; }
+        DeviceScope dev(m->device);
+        if (!dev.ok) { set_error("mdc_forward_q612: cannot select device %d", m->device); return MDC_EIO; }
+        return deployed_q612_forward(m, x_dev, x_is_q612 != 0, n, dense_dev, labels_dev, static_cast<hipStream_t>(hip_stream));
+    });
 }
 
 int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, int classes, int64_t* counts_dev, int64_t* bad_dev,
@@ -262,7 +301,16 @@ int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, 
     if (n < 0) { set_error("mdc_confusion: negative count"); return MDC_EINVAL; }
     if (n > 0 && (!truth_dev || !pred_dev)) { set_error("mdc_confusion: null labels"); return MDC_EINVAL; }
     if (!counts_dev) { set_error("mdc_confusion: null counts"); return MDC_EINVAL; }
-    return confusion_launch(truth_dev, pred_dev, n, classes, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream));
+    return confusion_launch(truth_dev, pred_dev, nullptr, n, classes, 1, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream));
+}
+
+int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, const int32_t* bin_dev, int64_t n, int classes, int bins,
+                         int64_t* counts_dev, int64_t* bad_dev, void* hip_stream) {
+    if (n < 0) { set_error("mdc_confusion_binned: negative count"); return MDC_EINVAL; }
+    if (n > 0 && (!truth_dev || !pred_dev || !bin_dev)) { set_error("mdc_confusion_binned: null labels"); return MDC_EINVAL; }
+    if (!counts_dev) { set_error("mdc_confusion_binned: null counts"); return MDC_EINVAL; }
+    if (bins < 1) { set_error("mdc_confusion_binned: bins must be >= 1 (got %d)", bins); return MDC_EINVAL; }
+    return confusion_launch(truth_dev, pred_dev, bin_dev, n, classes, bins, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream));
 }
 
 int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream) {
@@ -273,7 +321,16 @@ int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_
         set_error("mdc_iq_u8_to_frames: iq must be 4-byte and frames 8-byte aligned");
         return MDC_EINVAL;
     }
-    return iq_u8_launch(iq_dev, n, scale, x_dev, static_cast<hipStream_t>(hip_stream));
+    return iq_u8_launch(iq_dev, n, 128, scale, x_dev, static_cast<hipStream_t>(hip_stream));
+}
+
+int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale, float* x_dev, void* hip_stream) {
+    if (n < 0) { set_error("mdc_iq_u8_windows: negative window count"); return MDC_EINVAL; }
+    if (hop < 1 || hop > (int64_t)1 << 24) { set_error("mdc_iq_u8_windows: hop must be in 1..2^24 sample pairs (got %lld)", (long long)hop); return MDC_EINVAL; }
+    if (n == 0) return MDC_OK;
+    if (!iq_dev || !x_dev) { set_error("mdc_iq_u8_windows: null buffer"); return MDC_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(x_dev) & 7) != 0) { set_error("mdc_iq_u8_windows: frames must be 8-byte aligned"); return MDC_EINVAL; }
+    return iq_u8_launch(iq_dev, n, hop, scale, x_dev, static_cast<hipStream_t>(hip_stream));
 }
 
 int mdc_set_profiling(mdc_model* m, int on) {
@@ -290,24 +347,40 @@ const char* mdc_profile_name(const mdc_model* m, int slot) {
 }
 
 int mdc_profile_read(mdc_model* m, int slot, double* total_ms, int64_t* launches) {
-    if (!m || slot < 0 || slot >= (int)m->slots.size()) { set_error("mdc_profile_read: bad slot"); return MDC_EINVAL; }
-    ProfSlot& ps = m->slots[slot];
-    for (size_t i = 0; i + 1 < ps.ev.size(); i += 2) {
-        MDC_HIP(hipEventSynchronize(ps.ev[i + 1]));
-        float ms = 0.f;
-        MDC_HIP(hipEventElapsedTime(&ms, ps.ev[i], ps.ev[i + 1]));
-        ps.total_ms += ms;
-        ps.launches += 1;
-    }
-    for (hipEvent_t e : ps.ev) (void)hipEventDestroy(e);
-    ps.ev.clear();
-    if (total_ms) *total_ms = ps.total_ms;
-    if (launches) *launches = ps.launches;
-    return MDC_OK;
+    return guarded("mdc_profile_read", [&]() -> int {
+        if (!m || slot < 0 || slot >= (int)m->slots.size()) { set_error("mdc_profile_read: bad slot"); return MDC_EINVAL; }
+        ProfSlot& ps = m->slots[slot];
+        std::vector<hipEvent_t> ev;
+        {
+            std::lock_guard<std::mutex> g(m->prof_mu);
+            ev.swap(ps.ev);
+        }
+        double add_ms = 0;
+        int64_t add_n = 0;
+        int rc = MDC_OK;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev[i + 1]) != hipSuccess || hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) {
+                set_error("mdc_profile_read: event query failed");
+                rc = MDC_EIO;
+                break;
+            }
+            add_ms += ms;
+            add_n += 1;
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        std::lock_guard<std::mutex> g(m->prof_mu);
+        ps.total_ms += add_ms;
+        ps.launches += add_n;
+        if (total_ms) *total_ms = ps.total_ms;
+        if (launches) *launches = ps.launches;
+        return rc;
+    });
 }
 
 int mdc_profile_reset(mdc_model* m) {
     if (!m) { set_error("null model"); return MDC_EINVAL; }
+    std::lock_guard<std::mutex> g(m->prof_mu);
     for (ProfSlot& ps : m->slots) {
         for (hipEvent_t e : ps.ev) (void)hipEventDestroy(e);
         ps.ev.clear();

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,14 @@ constexpr int kW2 = 132;     // conv2 output width
 constexpr int kFeat = kC2 * kW2;   // 10560
 constexpr int kHid = 256;    // dense1 units
 
+// 8 raw bytes from an address that is only 2-byte aligned (a window of a uint8 I/Q capture at an arbitrary hop):
+// gfx950 global loads take unaligned addresses, and hipcc emits ONE global_load_dwordx2 for this
+__device__ __forceinline__ uint2 load8_unaligned(const unsigned char* p) {
+    uint2 r;
+    __builtin_memcpy(&r, p, 8);
+    return r;
+}
+
 struct ProfSlot {
     const char* name;
     std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -63,19 +72,26 @@ struct mdc_model {
     float fp8_input_absmax = 0.02f;
     int fp8_feat_scale_log2 = 0;
 
+    // profiling is the one piece of state mdc_forward touches on a finalized model: the event lists are guarded, so
+    // forwards of one model from several host threads stay safe with profiling on
     bool profiling = false;
     std::vector<mdc::ProfSlot> slots;
+    std::mutex prof_mu;
 };
 
 namespace mdc {
 
-// RAII-less helper: bracket a launch with events when profiling is on.
+// Bracket a launch with events when profiling is on.  The start event lives in the scope and the (start, stop) pair
+// is appended under the model's mutex, so concurrent forwards of one model never interleave their pairs.
 struct ProfScope {
     mdc_model* m;
     int slot;
     hipStream_t s;
+    hipEvent_t start = nullptr;
     ProfScope(const mdc_model* mm, int slot_, hipStream_t s_);
     ~ProfScope();
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
 };
 
 int upload(mdc_model* m, int idx, const void* host, size_t bytes);
@@ -85,19 +101,20 @@ int deployed_pack(mdc_model* m);
 // bf16 mode (dense layer on the matrix cores, lane = frame): deployed_bf16.hip
 int deployed_bf16_pack(mdc_model* m);
 int deployed_bf16_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s);
-int deployed_bf16_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s);
+int deployed_bf16_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int64_t hop, float scale, float* probs, int32_t* labels, hipStream_t s);
 // Q6.12 integer path of the deployed nets: deployed_q612.hip
 int deployed_q612_pack(mdc_model* m);
 int deployed_q612_forward(const mdc_model* m, const void* x, int x_is_q, int64_t n, int32_t* dense, int32_t* labels, hipStream_t s);
 // fp8 mode of the canonical VT-CNN2: vtcnn2_fp8_conv.hip
 int vtcnn2_fp8_pack(mdc_model* m);
-int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
+int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2 = 0, float scale = 0.f);
 // eval_ops.hip
-int confusion_launch(const int32_t* truth, const int32_t* pred, int64_t n, int classes, int64_t* counts, int64_t* bad, hipStream_t s);
-int iq_u8_launch(const uint8_t* iq, int64_t n, float scale, float* x, hipStream_t s);
+int confusion_launch(const int32_t* truth, const int32_t* pred, const int32_t* bin, int64_t n, int classes, int bins, int64_t* counts,
+                     int64_t* bad, hipStream_t s);
+int iq_u8_launch(const uint8_t* iq, int64_t n, int64_t hop, float scale, float* x, hipStream_t s);
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
                      float* tap, int tap_kind, hipStream_t s);
-int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s);
+int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int64_t hop, float scale, float* probs, int32_t* labels, hipStream_t s);
 
 // ---- cnn.py literal model (T4): cnnpy.hip ----------------------------------------------
 int cnnpy_pack(mdc_model* m);
@@ -109,5 +126,8 @@ int vtcnn2_pack(mdc_model* m);
 size_t vtcnn2_workspace_bytes(const mdc_model* m, int64_t n);
 int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
                    float* tap, int tap_kind, void* ws, size_t ws_bytes, hipStream_t s);
+// raw uint8 I/Q windows (window i = the 128 (I,Q) pairs from pair i*hop on) straight into the conv kernels' staging
+int vtcnn2_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int64_t hop, float scale, float* probs, int32_t* labels,
+                         void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace mdc

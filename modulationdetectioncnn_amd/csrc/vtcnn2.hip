@@ -54,11 +54,15 @@ constexpr int kXld = 133;              // LDS row stride of a padded input row (
 constexpr int kXinFloats = 4 * 2 * 16 * kXld;
 constexpr size_t kConvF32Lds = (2 * kWChunkFloats + kXinFloats) * sizeof(float);
 
+// U8 = true (mdc_forward_iq_u8): x points at raw interleaved uint8 (I,Q) pairs, window f at byte f*hop2; a lane loads
+// the 8 bytes holding its four samples of both rows and converts its row with iq_u8_kernel's arithmetic (eval_ops.hip).
+template <bool U8>
 __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __restrict__ x, long n,
                                                              const float* __restrict__ wpack,   // [16 chunks][7680]
                                                              const float* __restrict__ a1pack,  // [16 chunks][64 lanes]
                                                              const float* __restrict__ b2,      // [80]
-                                                             float* __restrict__ feat) {        // [n][132][80]
+                                                             float* __restrict__ feat,          // [n][132][80]
+                                                             long hop2, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wbuf = smem;
     float* xin = smem + 2 * kWChunkFloats;
@@ -74,7 +78,16 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
         for (int i = 0; i < 16; ++i) {
             const long f = frame0 + i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < n) v = reinterpret_cast<const float4*>(x + f * kFrameFloats)[lane];
+            if constexpr (U8) {
+                if (f < n) {
+                    const uint2 r = load8_unaligned(reinterpret_cast<const unsigned char*>(x) + f * hop2 + (lane & 31) * 8);
+                    const unsigned a = r.x >> (8 * h), b = r.y >> (8 * h);      // row 0 = I = even bytes, row 1 = Q = odd bytes
+                    v = make_float4(((float)(a & 0xFFu) - 127.5f) * scale, ((float)((a >> 16) & 0xFFu) - 127.5f) * scale,
+                                    ((float)(b & 0xFFu) - 127.5f) * scale, ((float)((b >> 16) & 0xFFu) - 127.5f) * scale);
+                }
+            } else {
+                if (f < n) v = reinterpret_cast<const float4*>(x + f * kFrameFloats)[lane];
+            }
             float* d = xw + (h * 16 + i) * kXld + 2 + s;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -254,7 +267,7 @@ int chain_launch(int t1, int nl, const float* x, long n, const float* wpack, int
 
 // ---- bf16 entry points (vtcnn2_bf16.hip) ------------------------------------------------
 int vtcnn2_bf16_pack(mdc_model* m);
-int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
+int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2 = 0, float scale = 0.f);
 int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s);
 
 // d_pack slots: 0 conv2 weights, 1 conv1 operand, 2 conv2 bias, 3 dense1 weights (permuted),
@@ -318,8 +331,9 @@ size_t vtcnn2_workspace_bytes(const mdc_model* m, int64_t n) {
     return np * kFeat * feat_elem(m) + np * kHid * sizeof(float);
 }
 
-int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
-                   float* tap, int tap_kind, void* ws, size_t ws_bytes, hipStream_t s) {
+// hop2 > 0: x points at raw uint8 I/Q windows hop2 bytes apart (mdc_forward_iq_u8); otherwise f32 frames
+static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale, int64_t n, float* probs, int32_t* labels,
+                      float* tap, int tap_kind, void* ws, size_t ws_bytes, hipStream_t s) {
     const size_t need = vtcnn2_workspace_bytes(m, n);
     if (!ws || ws_bytes < need) { set_error("vtcnn2 forward of %lld frames needs %zu workspace bytes (got %zu)", (long long)n, need, ws_bytes); return MDC_EINVAL; }
     if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) { set_error("workspace must be 256-byte aligned"); return MDC_EINVAL; }
@@ -329,19 +343,23 @@ int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, 
     const int C = m->topo.classes;
     int rc;
     if (m->dtype == MDC_BF16 || m->dtype == MDC_FP8) {
-        { ProfScope ps(m, 0, s); if ((rc = m->dtype == MDC_FP8 ? vtcnn2_fp8_conv(m, x, n, feat, s) : vtcnn2_bf16_conv(m, x, n, feat, s))) return rc; }
+        { ProfScope ps(m, 0, s); if ((rc = m->dtype == MDC_FP8 ? vtcnn2_fp8_conv(m, x, n, feat, s, hop2, scale) : vtcnn2_bf16_conv(m, x, n, feat, s, hop2, scale))) return rc; }
         { ProfScope ps(m, 1, s); if ((rc = vtcnn2_bf16_dense1(m, feat, n, hid, s))) return rc; }
     } else {
         {
             ProfScope ps(m, 0, s);
-            static bool attr_set = false;
-            if (!attr_set) {
-                MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds));
-                attr_set = true;
+            // per launch, like every other kernel here: the attribute is per DEVICE, and one process may drive several
+            if (hop2 > 0) {
+                MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds));
+                hipLaunchKernelGGL(vt_conv_f32_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), kConvF32Lds, s, x, (long)n,
+                                   static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]),
+                                   static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat), hop2, scale);
+            } else {
+                MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds));
+                hipLaunchKernelGGL(vt_conv_f32_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), kConvF32Lds, s, x, (long)n,
+                                   static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]),
+                                   static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat), 256L, 0.f);
             }
-            hipLaunchKernelGGL(vt_conv_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), kConvF32Lds, s, x, (long)n,
-                               static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]),
-                               static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat));
             MDC_HIP(hipGetLastError());
         }
         {
@@ -371,6 +389,18 @@ int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, 
         MDC_HIP(hipMemcpyAsync(tap, hid, (size_t)n * kHid * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return MDC_OK;
+}
+
+int vtcnn2_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
+                   float* tap, int tap_kind, void* ws, size_t ws_bytes, hipStream_t s) {
+    return vtcnn2_run(m, x, 0, 0.f, n, probs, labels, tap, tap_kind, ws, ws_bytes, s);
+}
+
+// raw SDR bytes straight into the conv kernels' staging: window i = the 128 (I,Q) pairs from
+// pair i*hop of one contiguous capture; no frame buffer in between.  Same workspace as mdc_forward.
+int vtcnn2_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int64_t hop, float scale, float* probs, int32_t* labels,
+                         void* ws, size_t ws_bytes, hipStream_t s) {
+    return vtcnn2_run(m, reinterpret_cast<const float*>(iq), 2 * (long)hop, scale, n, probs, labels, nullptr, MDC_TAP_NONE, ws, ws_bytes, s);
 }
 
 }  // namespace mdc

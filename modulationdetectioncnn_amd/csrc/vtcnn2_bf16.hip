@@ -319,11 +319,11 @@ int vtcnn2_bf16_pack(mdc_model* m) {
     return vtcnn2_bf16_pack_sched(m);      // operands of the asm-sequenced conv kernel (its own K order)
 }
 
-int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {
+int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2, float scale) {
     // default: the asm-sequenced kernel (vtcnn2_bf16_sched.hip); MDC_CONV_SCHED=0 selects the hipcc-scheduled one
-    // (same results up to summation order) for A/B timing
+    // (same results up to summation order) for A/B timing (f32 frames only: raw bytes always take the production kernel)
     static const bool sched = !(getenv("MDC_CONV_SCHED") && atoi(getenv("MDC_CONV_SCHED")) == 0);
-    if (sched) return vtcnn2_bf16_conv_sched(m, x, n, feat, s);
+    if (sched || hop2 > 0) return vtcnn2_bf16_conv_sched(m, x, n, feat, s, hop2, scale);
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds));

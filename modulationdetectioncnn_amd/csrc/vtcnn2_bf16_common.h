@@ -45,11 +45,31 @@ __device__ __forceinline__ float bf16_hi_as_f32(float a) {             // value 
 // again (multiplied by the low halves of the taps), kg 3 = constant (1,1) (bias slots; written once).
 // The two halves of it are separate so that the asm-sequenced kernel can issue the global load several steps
 // before it converts and stores the values (a load waited for right away sits behind every feature store in flight).
-__device__ __forceinline__ float4 stage_load(int k, const float* __restrict__ x, long n, long frame0, int tid) {
+// U8 = true (mdc_forward_iq_u8): x points at raw interleaved unsigned 8-bit (I,Q) pairs of one contiguous capture;
+// window f starts hop2 = 2*hop bytes after window f-1 (hop = 128 pairs: disjoint 256-byte frames).  The lane loads the
+// 8 bytes that hold its four samples of BOTH rows (lanes l and l+32 read the same address; only 2-byte alignment is
+// guaranteed -- gfx950 global loads take unaligned addresses) and stage_decode converts the row it owns with the
+// arithmetic of iq_u8_kernel (eval_ops.hip), so everything downstream is bit-identical to convert-then-forward.
+template <bool U8> struct StageRaw { using type = float4; };
+template <> struct StageRaw<true> { using type = uint2; };
+template <bool U8 = false>
+__device__ __forceinline__ typename StageRaw<U8>::type stage_load(int k, const float* __restrict__ x, long n, long frame0, int tid, long hop2 = 256) {
     const int idx = tid + 256 * k;
     const long f = frame0 + (idx >> 6);
     // unconditional (clamped) load: a load under an exec mask gets its s_waitcnt vmcnt(0) right at the join
-    return reinterpret_cast<const float4*>(x + (f < n ? f : n - 1) * kFrameFloats)[idx & 63];
+    if constexpr (U8) return load8_unaligned(reinterpret_cast<const unsigned char*>(x) + (f < n ? f : n - 1) * hop2 + (idx & 31) * 8);
+    else return reinterpret_cast<const float4*>(x + (f < n ? f : n - 1) * kFrameFloats)[idx & 63];
+}
+template <bool U8 = false>
+__device__ __forceinline__ float4 stage_decode(typename StageRaw<U8>::type r, int tid, float scale) {
+    if constexpr (U8) {
+        const unsigned sh = ((tid >> 5) & 1) * 8;      // row 0 = I = even bytes, row 1 = Q = odd bytes
+        const unsigned a = r.x >> sh, b = r.y >> sh;
+        return make_float4(((float)(a & 0xFFu) - 127.5f) * scale, ((float)((a >> 16) & 0xFFu) - 127.5f) * scale,
+                           ((float)(b & 0xFFu) - 127.5f) * scale, ((float)((b >> 16) & 0xFFu) - 127.5f) * scale);
+    } else {
+        return r;
+    }
 }
 __device__ __forceinline__ void stage_write(int k, float4 v, long n, long frame0, unsigned* __restrict__ im, int tid) {
     const int idx = tid + 256 * k;
@@ -69,9 +89,10 @@ __device__ __forceinline__ void stage_write(int k, float4 v, long n, long frame0
         d[32] = hi;
     }
 }
+template <bool U8 = false>
 __device__ __forceinline__ void stage_quarter(int k, const float* __restrict__ x, long n, long frame0,
-                                              unsigned* __restrict__ im, int tid) {
-    stage_write(k, stage_load(k, x, n, frame0, tid), n, frame0, im, tid);
+                                              unsigned* __restrict__ im, int tid, long hop2 = 256, float scale = 0.f) {
+    stage_write(k, stage_decode<U8>(stage_load<U8>(k, x, n, frame0, tid, hop2), tid, scale), n, frame0, im, tid);
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -97,7 +118,8 @@ inline float bf2f(unsigned short h) {
 }  // namespace
 
 // launcher of the asm-sequenced conv kernel (vtcnn2_bf16_sched.hip); same arguments as vtcnn2_bf16_conv
-int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s);
+// (hop2 > 0: x points at raw uint8 I/Q, windows hop2 bytes apart, samples (byte - 127.5) * scale)
+int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2 = 0, float scale = 0.f);
 // its operand packing (d_pack slots 6 and 7); called by vtcnn2_bf16_pack
 int vtcnn2_bf16_pack_sched(mdc_model* m);
 

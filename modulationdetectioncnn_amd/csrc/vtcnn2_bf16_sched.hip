@@ -221,10 +221,11 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
 #undef HANDOFF
 }
 
-template <int ABL>
+template <int ABL, bool U8 = false>
 __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float* __restrict__ x, long n,
                                                                     const u32x4* __restrict__ wq, const u32x4* __restrict__ a1q,
-                                                                    const float* __restrict__ b2, unsigned short* __restrict__ feat) {
+                                                                    const float* __restrict__ b2, unsigned short* __restrict__ feat,
+                                                                    long hop2 = 256, float scale = 0.f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* img = reinterpret_cast<unsigned*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
     const long ngroups = (n + 15) >> 4;
     long grp = blockIdx.x;
     if (grp < ngroups)
-        for (int k = 0; k < 4; ++k) sch_stage_write(k, stage_load(k, x, n, grp * 16, tid), n, grp * 16, img, tid);
+        for (int k = 0; k < 4; ++k) sch_stage_write(k, stage_decode<U8>(stage_load<U8>(k, x, n, grp * 16, tid, hop2), tid, scale), n, grp * 16, img, tid);
     __syncthreads();
 
     int buf = 0;
@@ -309,12 +310,12 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
 
         sch_step<0, true, false, ABL>(st, 0, q, fbase, acc);
         int v = 1;
-        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        typename StageRaw<U8>::type sv{};
         for (int it = 0; it < 10; ++it, v += 12) {     // v = 1 .. 120
             // next group's frames -> the other image buffer, a quarter per iteration; each quarter's global load is
             // issued one iteration (12 steps) before its conversion and LDS writes
-            if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, sv, n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
-            if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load(it - 5, x, n, gnext * 16, tid);
+            if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, stage_decode<U8>(sv, tid, scale), n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
+            if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load<U8>(it - 5, x, n, gnext * 16, tid, hop2);
             sch_step<1, false, false, ABL>(st, v + 0, q, fbase, acc);
             sch_step<2, false, false, ABL>(st, v + 1, q, fbase, acc);
             sch_step<3, false, false, ABL>(st, v + 2, q, fbase, acc);
@@ -413,14 +414,22 @@ int vtcnn2_bf16_pack_sched(mdc_model* m) {
     return upload(m, 7, a1.data(), a1.size() * 2);
 }
 
-int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {
+int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2, float scale) {
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
+    if (hop2 > 0) {      // raw uint8 I/Q straight into the staging
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_sched_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
+        hipLaunchKernelGGL((vt_conv_bf16_sched_kernel<0, true>), dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
+                           static_cast<const u32x4*>(m->d_pack[6]), static_cast<const u32x4*>(m->d_pack[7]),
+                           static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2, scale);
+        MDC_HIP(hipGetLastError());
+        return MDC_OK;
+    }
 #define MDC_LAUNCH_SCHED(A) do { \
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_sched_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
     hipLaunchKernelGGL(vt_conv_bf16_sched_kernel<A>, dim3(grid), dim3(256), kSchedLds, s, x, (long)n, \
                        static_cast<const u32x4*>(m->d_pack[6]), static_cast<const u32x4*>(m->d_pack[7]), \
-                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat)); } while (0)
+                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), 256L, 0.f); } while (0)
 #ifdef MDC_ABLATIONS   // timing-only variants for tools/ablate_sched.py (build with -DMDC_ABLATIONS); results are wrong
     static const int abl = getenv("MDC_ABLATE_S") ? atoi(getenv("MDC_ABLATE_S")) : 0;
     switch (abl) { case 1: MDC_LAUNCH_SCHED(1); break; case 2: MDC_LAUNCH_SCHED(2); break; case 3: MDC_LAUNCH_SCHED(3); break;

@@ -143,9 +143,11 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
 #undef HANDOFF
 }
 
+template <bool U8>
 __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __restrict__ x, long n,
                                                              const u32x8* __restrict__ wq, const u32x4* __restrict__ a1q,
-                                                             const float* __restrict__ b2, unsigned short* __restrict__ feat) {
+                                                             const float* __restrict__ b2, unsigned short* __restrict__ feat,
+                                                             long hop2, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* img = reinterpret_cast<unsigned*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     const long ngroups = (n + 15) >> 4;
     long grp = blockIdx.x;
     if (grp < ngroups)
-        for (int k = 0; k < 4; ++k) sch_stage_write(k, stage_load(k, x, n, grp * 16, tid), n, grp * 16, img, tid);
+        for (int k = 0; k < 4; ++k) sch_stage_write(k, stage_decode<U8>(stage_load<U8>(k, x, n, grp * 16, tid, hop2), tid, scale), n, grp * 16, img, tid);
     __syncthreads();
 
     int buf = 0;
@@ -222,10 +224,10 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
 
         f8_step<0, true, false>(st, 0, q, fbase, acc);
         int v = 1;
-        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        typename StageRaw<U8>::type sv{};
         for (int it = 0; it < 10; ++it, v += 12) {     // v = 1 .. 120
-            if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, sv, n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
-            if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load(it - 5, x, n, gnext * 16, tid);
+            if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, stage_decode<U8>(sv, tid, scale), n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
+            if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load<U8>(it - 5, x, n, gnext * 16, tid, hop2);
             f8_step<1, false, false>(st, v + 0, q, fbase, acc);
             f8_step<2, false, false>(st, v + 1, q, fbase, acc);
             f8_step<3, false, false>(st, v + 2, q, fbase, acc);
@@ -362,13 +364,20 @@ int vtcnn2_fp8_pack(mdc_model* m) {
     return upload(m, 3, w1t.data(), w1t.size() * 2);
 }
 
-int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s) {
+int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2, float scale) {
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
-    hipLaunchKernelGGL(vt_conv_fp8_kernel, dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
-                       static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]),
-                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat));
+    if (hop2 > 0) {      // raw uint8 I/Q straight into the staging
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
+        hipLaunchKernelGGL(vt_conv_fp8_kernel<true>, dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
+                           static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]),
+                           static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2, scale);
+    } else {
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
+        hipLaunchKernelGGL(vt_conv_fp8_kernel<false>, dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
+                           static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]),
+                           static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), 256L, 0.f);
+    }
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

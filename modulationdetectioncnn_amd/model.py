@@ -52,7 +52,9 @@ class VTCNN2:
         self.fp8_input_absmax = fp8_input_absmax
         if dtype not in _DTYPE:
             raise ValueError(f"dtype must be one of {sorted(_DTYPE)}")
-        self._device = device
+        # the device is resolved ONCE (None = the device current at construction): the engine handle, the workspace
+        # and the input check all use this stored ordinal, whatever torch.cuda.set_device() does later
+        self._device_index: Optional[int] = self._resolve_device(device)
         self._weights: Optional[Weights] = None
         self._handle: Optional[C.c_void_p] = None
         self._ws = {}
@@ -150,15 +152,25 @@ class VTCNN2:
         return [(k.copy(), b.copy()) for k, b in self._weights]
 
     # ------------------------------------------------------------------ engine
+    @staticmethod
+    def _resolve_device(device) -> Optional[int]:
+        """int | "cuda:N" | torch.device | None.  None is resolved when a GPU is present (at construction, else at
+        first use: models are also built on GPU-less hosts to read or convert weights)."""
+        if isinstance(device, (int, np.integer)):
+            return int(device)
+        torch = _torch()
+        if device is None:
+            return torch.cuda.current_device() if torch.cuda.is_available() else None
+        d = torch.device(device)
+        if d.type != "cuda":
+            raise ValueError(f"the MI355X path needs a cuda (ROCm) device, got {device!r}")
+        return d.index if d.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else None)
+
     @property
     def device_index(self) -> int:
-        torch = _torch()
-        d = self._device
-        if d is None:
-            return torch.cuda.current_device()
-        if isinstance(d, int):
-            return d
-        return torch.device(d).index or 0
+        if self._device_index is None:
+            self._device_index = _torch().cuda.current_device()
+        return self._device_index
 
     def _engine(self) -> C.c_void_p:
         if self._handle is not None:
@@ -327,9 +339,10 @@ class VTCNN2:
         return float(np.trace(conf) / max(conf.sum(), 1.0))
 
     def accuracy_by_snr(self, X, labels_true, snrs, batch_size: Optional[int] = None) -> Tuple[Dict, Dict]:
-        """The per-SNR loop of cnn.py:228-259: one forward over the whole batch, then for every distinct value of
-        `snrs` (one per frame) the confusion counts of that subset (device side) and acc[snr] = cor / (cor + ncor).
-        Returns (acc, conf): dicts keyed by SNR value; conf[snr] is the un-normalised C x C count matrix (numpy)."""
+        """The per-SNR loop of cnn.py:228-259: one forward over the whole batch, then ONE launch
+        (mdc_confusion_binned: an S x C x C histogram keyed by each frame's SNR bin) and one device->host copy for all
+        SNR values; acc[snr] = cor / (cor + ncor) (cnn.py:257-259).  Returns (acc, conf): dicts keyed by SNR value;
+        conf[snr] is the un-normalised C x C count matrix (numpy)."""
         torch = _torch()
         x = X if isinstance(X, torch.Tensor) else torch.from_numpy(
             np.ascontiguousarray(np.asarray(X), dtype=np.float32)).to(f"cuda:{self.device_index}")
@@ -341,22 +354,43 @@ class VTCNN2:
         if truth.shape != pred.shape or snr_t.shape != pred.shape:
             raise ValueError("labels_true and snrs need one entry per frame")
         Cn = self.topology.classes
+        if pred.numel() == 0:
+            return {}, {}
+        values, bins = torch.unique(snr_t, sorted=True, return_inverse=True)      # SNR value -> bin index (plumbing)
+        bins = bins.to(torch.int32).contiguous()
+        S = int(values.numel())
+        counts = torch.zeros((S, Cn, Cn), dtype=torch.int64, device=dev)
+        bad = torch.zeros((1,), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _cabi.check(_cabi.lib().mdc_confusion_binned(truth.data_ptr(), pred.data_ptr(), bins.data_ptr(), pred.numel(), Cn, S,
+                                                         counts.data_ptr(), bad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        host = torch.cat([counts.view(-1), bad]).cpu().numpy()      # the one synchronising copy
+        if int(host[-1]):
+            raise ValueError(f"{int(host[-1])} labels lie outside [0, {Cn})")
+        c_all = host[:-1].reshape(S, Cn, Cn)
         acc, conf = {}, {}
-        L = _cabi.lib()
-        for val in torch.unique(snr_t).tolist():
-            idx = (snr_t == val).nonzero().flatten()
-            t_i, p_i = truth[idx].contiguous(), pred[idx].contiguous()
-            counts = torch.zeros((Cn, Cn), dtype=torch.int64, device=dev)
-            bad = torch.zeros((1,), dtype=torch.int64, device=dev)
-            with torch.cuda.device(dev):
-                _cabi.check(L.mdc_confusion(t_i.data_ptr(), p_i.data_ptr(), t_i.numel(), Cn, counts.data_ptr(), bad.data_ptr(),
-                                            torch.cuda.current_stream(dev).cuda_stream))
-            if int(bad.item()):
-                raise ValueError(f"{int(bad.item())} labels lie outside [0, {Cn})")
-            c = counts.cpu().numpy()
-            conf[val] = c
-            acc[val] = float(np.trace(c)) / float(max(c.sum(), 1))
+        for i, val in enumerate(values.tolist()):
+            conf[val] = c_all[i]
+            acc[val] = float(np.trace(c_all[i])) / float(max(c_all[i].sum(), 1))
         return acc, conf
+
+    @staticmethod
+    def save_results(path: str, acc: Dict, tag: str = "CNN2", dr: float = 0.5) -> None:
+        """The results file of cnn.py:262-264: `cPickle.dump(("CNN2", 0.5, acc), fd)` -- the tuple (model tag, dropout
+        rate, {snr: accuracy}) that the reference's plotting cells read back.  Written with pickle protocol 2 (what
+        Python 2's cPickle reads); keys and values are plain Python numbers."""
+        import pickle
+        clean = {(int(k) if float(k).is_integer() else float(k)): float(v) for k, v in acc.items()}
+        with open(path, "wb") as fd:
+            pickle.dump((str(tag), float(dr), clean), fd, protocol=2)
+
+    @staticmethod
+    def load_results(path: str) -> Tuple[str, float, Dict]:
+        """Read back a file written by save_results (a file this package wrote itself; never one shipped by others)."""
+        import pickle
+        with open(path, "rb") as fd:
+            tag, dr, acc = pickle.load(fd)
+        return tag, dr, acc
 
     # ------------------------------------------------------------------ FPGA arithmetic (SURVEY.md 8(f) item 1)
     def predict_q612(self, X, as_float: bool = True):
@@ -382,34 +416,44 @@ class VTCNN2:
         return (out.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (out, labels)
 
     # ------------------------------------------------------------------ raw SDR bytes
-    def predict_iq_u8(self, iq, scale: Optional[float] = None, batch_size: int = 0):
-        """`predict` on raw RTL-SDR samples: iq holds 256*n unsigned bytes (I0,Q0,I1,Q1,...), each sample becomes
-        (byte - 127.5) * scale (default 1/127.5).  Deployed nets read the bytes in the forward kernel itself
-        (mdc_forward_iq_u8: 256 B of HBM input per frame, no frame buffer); the other topologies convert on the
-        device first (frames_from_iq_u8) -- the results are bit-identical either way.  Returns (probs, labels) as
-        device tensors for a device tensor input, numpy arrays otherwise."""
+    def predict_iq_u8(self, iq, scale: Optional[float] = None, batch_size: int = 0, hop: int = 128):
+        """`predict` on raw RTL-SDR samples: iq holds unsigned bytes (I0,Q0,I1,Q1,...), each sample becomes
+        (byte - 127.5) * scale (default 1/127.5).  Window i is the 128 (I,Q) pairs starting at pair i*hop of the
+        capture: hop = 128 cuts it into disjoint 256-byte frames (then the byte count must be a multiple of 256),
+        a smaller hop slides the classifier over a live stream (n = (pairs - 128) // hop + 1 windows).  The deployed
+        nets and the VT-CNN2 family read the bytes in the forward kernels themselves (mdc_forward_iq_u8: 2*hop B of
+        HBM input per window, no frame buffer); cnn.py's literal model converts on the device first
+        (frames_from_iq_u8) -- the results are bit-identical either way.  Returns (probs, labels) as device tensors
+        for a device tensor input, numpy arrays otherwise."""
         torch = _torch()
-        from .frontend import DEFAULT_SCALE, frames_from_iq_u8
+        from .frontend import DEFAULT_SCALE, frames_from_iq_u8, window_count
         scale = DEFAULT_SCALE if scale is None else float(scale)
         as_numpy = not isinstance(iq, torch.Tensor)
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(iq, dtype=np.uint8))) if as_numpy else iq
         if t.dtype != torch.uint8:
             raise TypeError(f"iq must be uint8, got {t.dtype}")
         t = t.to(f"cuda:{self.device_index}").contiguous().view(-1)
-        if t.numel() % 256:
-            raise ValueError(f"{t.numel()} bytes is not a whole number of 256-byte frames")
-        n, Cn = t.numel() // 256, self.topology.classes
-        if self.topology.kind == "deployed":
-            probs = torch.empty((n, Cn), dtype=torch.float32, device=t.device)
-            labels = torch.empty((n,), dtype=torch.int32, device=t.device)
-            with torch.cuda.device(t.device):
-                _cabi.check(_cabi.lib().mdc_forward_iq_u8(self._engine(), t.data_ptr() if n else None, n, scale, probs.data_ptr(),
-                                                          labels.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream))
+        n, Cn = window_count(t.numel(), hop), self.topology.classes
+        if t.data_ptr() % 2:
+            t = t.clone()       # a view into a larger buffer starting at an odd byte: the ABI wants whole (I,Q) pairs
+        probs = torch.empty((n, Cn), dtype=torch.float32, device=t.device)
+        labels = torch.empty((n,), dtype=torch.int32, device=t.device)
+        if n == 0:
+            return (probs.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (probs, labels)
+        if self.topology.kind == "cnnpy":
+            x = frames_from_iq_u8(t, scale, hop=hop)
+            self.forward_device(x, probs, labels, batch_size=batch_size or None)
         else:
-            x = frames_from_iq_u8(t, scale)
-            probs = torch.empty((n, Cn), dtype=torch.float32, device=t.device)
-            labels = torch.empty((n,), dtype=torch.int32, device=t.device)
-            self.forward_device(x, probs, labels, batch_size=batch_size or 65536)
+            L, h = _cabi.lib(), self._engine()
+            chunk = max(1, min(int(batch_size) if batch_size else self.default_chunk, n))
+            with torch.cuda.device(t.device):
+                ws, ws_bytes = self._workspace(chunk)
+                stream = torch.cuda.current_stream(t.device).cuda_stream
+                for s0 in range(0, n, chunk):
+                    m = min(chunk, n - s0)
+                    _cabi.check(L.mdc_forward_iq_u8(h, t.data_ptr() + 2 * hop * s0, m, hop, scale,
+                                                    probs.data_ptr() + s0 * Cn * 4, labels.data_ptr() + s0 * 4,
+                                                    ws.data_ptr() if ws is not None else None, ws_bytes, stream))
         return (probs.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (probs, labels)
 
     # ------------------------------------------------------------------ measurement hooks

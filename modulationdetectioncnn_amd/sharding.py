@@ -1,10 +1,15 @@
-"""Multi-GPU: frames are independent, so a batch shards across ranks with NO data-path collective.
+"""Multi-GPU: frames are independent, so a batch shards across GPUs with NO data-path collective.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL on the GPUs, "gloo" in the CPU
-tests).  Rank g owns the contiguous slice [g*N/G, (g+1)*N/G) of the batch; the
-weights (<= 11.3 MB) are replicated by each rank's own load.  The only collectives are OFF the
-data path: the barriers around a timed region, the MAX of the elapsed times, and an optional
-gather of the (N,) labels / (N,C) probabilities when a caller wants them in one place.
+Two drivers over the same partition (shard g of G = the contiguous slice [g*N/G, (g+1)*N/G), SURVEY.md 8(e);
+weights, <= 11.3 MB, replicated per GPU):
+
+* one process per GPU (`ShardedPredictor`, `timed_region`; torch.distributed, backend "nccl" = RCCL on the GPUs,
+  "gloo" in the CPU tests) -- the form bench.py's contract launches.  The only collectives are OFF the data path:
+  the barriers around a timed region, the MAX of the elapsed times, and an optional gather of the (N,) labels /
+  (N,C) probabilities when a caller wants them in one place;
+* ONE process, one model handle and one HIP stream per GPU (`MultiStreamPredictor`) -- BASELINE.json configs[3]'s
+  "per-GPU HIP streams": a single host thread enqueues every shard's forward on its device's stream, then
+  synchronises each stream once.  No collective at all; mdc_forward never synchronises, so the G forwards overlap.
 """
 from __future__ import annotations
 
@@ -78,8 +83,13 @@ class ShardedPredictor:
 
     @classmethod
     def for_model(cls, model) -> "ShardedPredictor":
+        """This rank's shard through a VTCNN2 bound to this rank's GPU: ONE upload, ONE forward (forward_device returns
+        probabilities and labels of the same pass), one copy back per output."""
         def engine(x):
-            return model.predict(x), model.predict_classes(x)
+            import torch
+            xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(f"cuda:{model.device_index}")
+            probs, labels, _ = model.forward_device(xt)
+            return probs.cpu().numpy(), labels.cpu().numpy()
         return cls(engine, model.topology.classes)
 
     def predict_local(self, X: np.ndarray) -> Tuple[Tuple[int, int], np.ndarray, np.ndarray]:
@@ -101,6 +111,78 @@ class ShardedPredictor:
         parts.sort(key=lambda t: t[0][0])
         assert [b for b, _, _ in parts] == shard_bounds(len(X), self.world)
         return np.concatenate([q for _, q, _ in parts]), np.concatenate([q for _, _, q in parts])
+
+
+class GpuLane:
+    """One (model handle, HIP stream) pair of the one-process driver.  `forward` enqueues on the lane's stream and
+    returns device tensors without synchronising; `sync` waits for the lane's stream."""
+
+    def __init__(self, model, stream=None):
+        import torch
+        self.model = model
+        self.device = torch.device("cuda", model.device_index)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+
+    def upload(self, x: np.ndarray):
+        import torch
+        with torch.cuda.stream(self.stream):
+            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.device, non_blocking=True)
+
+    def forward(self, x):
+        import torch
+        with torch.cuda.stream(self.stream):
+            probs, labels, _ = self.model.forward_device(x)
+        return probs, labels
+
+    def sync(self) -> None:
+        self.stream.synchronize()
+
+    def download(self, t) -> np.ndarray:
+        return t.cpu().numpy()
+
+
+class MultiStreamPredictor:
+    """BASELINE.json configs[3] as north_star words it: ONE process, G lanes (one model handle + one HIP stream per
+    GPU), frames sharded contiguously over the lanes, every forward enqueued from one host thread, each lane
+    synchronised ONCE at the end.  Lanes are anything with upload / forward / sync / download (GpuLane on the GPUs; the
+    CPU tests inject a recording fake).  Several lanes may share a device (two streams of one GPU)."""
+
+    def __init__(self, lanes, classes: int):
+        if not lanes:
+            raise ValueError("need at least one lane")
+        self.lanes = list(lanes)
+        self.classes = classes
+
+    @classmethod
+    def for_models(cls, models, streams_per_device: int = 1) -> "MultiStreamPredictor":
+        """models: one finalized-on-first-use VTCNN2 per GPU (same weights, different `device`)."""
+        models = list(models)
+        lanes = [GpuLane(m) for m in models for _ in range(streams_per_device)]
+        return cls(lanes, models[0].topology.classes)
+
+    def plan(self, n: int) -> List[Tuple[int, int, int]]:
+        """[(lane, lo, hi)]: the contiguous, ordered, exhaustive partition of n frames over the lanes."""
+        return [(g, lo, hi) for g, (lo, hi) in enumerate(shard_bounds(n, len(self.lanes)))]
+
+    def forward_shards(self, shards):
+        """shards[g]: lane g's frames, already resident on lane g's device.  Enqueues all, syncs each lane once;
+        returns [(probs, labels)] per lane (device tensors)."""
+        if len(shards) != len(self.lanes):
+            raise ValueError(f"{len(shards)} shards for {len(self.lanes)} lanes")
+        outs = [lane.forward(x) for lane, x in zip(self.lanes, shards)]      # no sync inside: the G forwards overlap
+        for lane in self.lanes:
+            lane.sync()
+        return outs
+
+    def predict(self, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Host batch in, host results out (plumbing: PCIe-bound).  Uploads, forwards and syncs per lane as above."""
+        X = np.asarray(X)
+        plan = self.plan(len(X))
+        xs = [self.lanes[g].upload(X[lo:hi]) for g, lo, hi in plan]
+        outs = self.forward_shards(xs)
+        p = [np.asarray(self.lanes[g].download(o[0]), np.float32).reshape(-1, self.classes) for (g, _, _), o in zip(plan, outs)]
+        l = [np.asarray(self.lanes[g].download(o[1]), np.int32).reshape(-1) for (g, _, _), o in zip(plan, outs)]
+        return np.concatenate(p), np.concatenate(l)
 
 
 def confusion_counts(labels_true: np.ndarray, labels_pred: np.ndarray, classes: int, reduce: bool = True) -> np.ndarray:

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(lib)
     for name in _declared():
         assert hasattr(L, name), name
-    assert L.mdc_abi_version() == 1
+    assert L.mdc_abi_version() == _cabi.ABI_VERSION == 2
 
 
 def test_binding_loads_and_reports_errors_without_gpu():

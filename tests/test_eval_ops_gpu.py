@@ -111,25 +111,97 @@ def test_fused_raw_iq_extreme_bytes_and_default_scale():
     assert float(x.min()) == -1.0 and float(x.max()) == 1.0
 
 
+def _windows_np(iq, hop, scale):
+    """mdc_iq_u8_windows restated in numpy float32: window i = pairs [i*hop, i*hop + 128)."""
+    pairs = iq.reshape(-1, 2)
+    n = 0 if len(pairs) < 128 else (len(pairs) - 128) // hop + 1
+    idx = (np.arange(n)[:, None] * hop + np.arange(128)[None, :])
+    w = pairs[idx].astype(np.float32)                    # (n,128,2)
+    sc = np.float32(scale)
+    return np.stack([(w[:, :, 0] - np.float32(127.5)) * sc, (w[:, :, 1] - np.float32(127.5)) * sc], axis=1)
+
+
+@pytest.mark.parametrize("hop", [128, 64, 7, 1])
+def test_iq_u8_windows_are_bit_exact(hop):
+    rng = np.random.default_rng(hop)
+    iq = rng.integers(0, 256, size=2 * (128 + hop * 300), dtype=np.uint8)
+    x = frames_from_iq_u8(iq, 0.01, hop=hop)
+    want = _windows_np(iq, hop, 0.01)
+    assert x.shape == want.shape == (301, 2, 128)
+    np.testing.assert_array_equal(x.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("name", ["3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"])
+@pytest.mark.parametrize("hop", [128, 64, 8, 3, 1])
+def test_sliding_windows_fused_equals_convert_then_forward(name, dtype, hop):
+    """A live capture classified every `hop` sample pairs (README.md:5): the forward kernel reading the overlapping
+    windows straight from the byte stream == mdc_iq_u8_windows + mdc_forward, bit for bit (odd hops leave the windows
+    2-byte aligned only)."""
+    import os
+    from conftest import GOLDEN
+    m = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype=dtype)
+    for n in (1, 64, 65, 1000, 4097):
+        rng = np.random.default_rng(1000 * hop + n)
+        iq = rng.integers(0, 256, size=2 * (128 + hop * (n - 1)), dtype=np.uint8)
+        t = torch.from_numpy(iq).cuda()
+        scale = 0.02 / 127.5
+        probs, labels = m.predict_iq_u8(t, scale, hop=hop)
+        assert probs.shape == (n, 3)
+        p2, l2, _ = m.forward_device(frames_from_iq_u8(t, scale, hop=hop))
+        assert torch.equal(probs, p2) and torch.equal(labels, l2), (hop, n)
+        # chunked (chunk boundaries at arbitrary windows): same bits
+        p3, l3 = m.predict_iq_u8(t, scale, hop=hop, batch_size=97)
+        assert torch.equal(probs, p3) and torch.equal(labels, l3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
+@pytest.mark.parametrize("hop", [128, 64, 5, 1])
+def test_vtcnn2_reads_raw_bytes_in_its_conv_staging(dtype, hop):
+    """(f)3 for the canonical VT-CNN2: the conv kernels' frame staging converts the uint8 pairs itself; logits-level
+    outputs (probabilities, labels) are bit-identical to convert-then-forward."""
+    m = VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, device=0, dtype=dtype)
+    scale = 0.02 / 127.5
+    for n in (1, 16, 17, 100, 700):
+        rng = np.random.default_rng(77 * hop + n)
+        iq = rng.integers(0, 256, size=2 * (128 + hop * (n - 1)), dtype=np.uint8)
+        t = torch.from_numpy(iq).cuda()
+        probs, labels = m.predict_iq_u8(t, scale, hop=hop)
+        p2, l2, _ = m.forward_device(frames_from_iq_u8(t, scale, hop=hop))
+        assert probs.shape == (n, 11) and torch.equal(probs, p2) and torch.equal(labels, l2), (dtype, hop, n)
+    p3, l3 = m.predict_iq_u8(t, scale, hop=hop, batch_size=48)
+    assert torch.equal(p3, p2) and torch.equal(l3, l2)
+
+
 def test_raw_iq_other_topologies_and_rejects():
-    """VT-CNN2 takes raw bytes through the device-side conversion (same call); the fused C entry refuses it."""
+    """cnn.py's literal model takes raw bytes through the device-side conversion (same Python call); the fused C entry
+    refuses it; bad arguments are errors, not crashes."""
     from modulationdetectioncnn_amd import _cabi
     iq = np.random.default_rng(5).integers(0, 256, size=256 * 40, dtype=np.uint8)
-    m = VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, device=0, dtype="f32")
+    m = VTCNN2.synthetic("cnnpy", classes=5, seed=2016, device=0)
     probs, labels = m.predict_iq_u8(iq, 0.02 / 127.5)
     want = m.predict(frames_from_iq_u8(iq, 0.02 / 127.5))
     np.testing.assert_array_equal(probs, want.cpu().numpy())
     t = torch.from_numpy(iq).cuda()
-    out = torch.empty((40, 11), dtype=torch.float32, device="cuda")
-    rc = _cabi.lib().mdc_forward_iq_u8(m._engine(), t.data_ptr(), 40, 1.0, out.data_ptr(), None, None)
-    assert rc == -95 and b"deployed" in _cabi.lib().mdc_last_error()
+    out = torch.empty((40, 5), dtype=torch.float32, device="cuda")
+    L = _cabi.lib()
+    rc = L.mdc_forward_iq_u8(m._engine(), t.data_ptr(), 40, 128, 1.0, out.data_ptr(), None, None, 0, None)
+    assert rc == -95 and b"deployed" in L.mdc_last_error()
     d = _t1()
     with pytest.raises(ValueError):
         d.predict_iq_u8(np.zeros(300, np.uint8))
+    with pytest.raises(ValueError):
+        d.predict_iq_u8(np.zeros(301, np.uint8), hop=5)          # half a pair
     with pytest.raises(TypeError):
         d.predict_iq_u8(torch.zeros(256, dtype=torch.int16))
-    with pytest.raises(_cabi.MdcError):          # misaligned byte pointer
-        _cabi.check(_cabi.lib().mdc_forward_iq_u8(d._engine(), t.data_ptr() + 4, 1, 1.0, None, None, None))
+    with pytest.raises(_cabi.MdcError):          # odd byte pointer: not a whole (I,Q) pair
+        _cabi.check(L.mdc_forward_iq_u8(d._engine(), t.data_ptr() + 1, 1, 128, 1.0, None, None, None, 0, None))
+    with pytest.raises(_cabi.MdcError):          # hop < 1
+        _cabi.check(L.mdc_forward_iq_u8(d._engine(), t.data_ptr(), 1, 0, 1.0, None, None, None, 0, None))
+    v = VTCNN2.synthetic(Topology.vtcnn2(3), seed=1, device=0, dtype="bf16")
+    with pytest.raises(_cabi.MdcError):          # vtcnn2 without its workspace
+        _cabi.check(L.mdc_forward_iq_u8(v._engine(), t.data_ptr(), 16, 128, 1.0, None, None, None, 0, None))
+    assert d.predict_iq_u8(np.zeros(100, np.uint8), hop=3)[0].shape == (0, 3)      # capture shorter than one window
 
 
 def test_iq_u8_rejects_partial_frames():
@@ -158,3 +230,64 @@ def test_accuracy_by_snr_matches_the_reference_loop():
         np.testing.assert_array_equal(conf[snr], want.astype(np.int64))
         assert acc[snr] == pytest.approx(1.0 * cor / (cor + ncor))
     assert set(acc) == set(snrs.tolist())
+
+
+@pytest.mark.parametrize("classes,bins,n", [(3, 5, 5000), (11, 20, 100003), (32, 40, 20000), (2, 1, 10)])
+def test_binned_confusion_one_launch_matches_the_literal_loop(classes, bins, n):
+    """mdc_confusion_binned (LDS histogram, or global atomics when bins*C*C exceeds the LDS table: 40 x 32 x 32)."""
+    from modulationdetectioncnn_amd import _cabi
+    rng = np.random.default_rng(classes * 100 + bins)
+    truth = rng.integers(0, classes, size=n).astype(np.int32)
+    pred = rng.integers(0, classes, size=n).astype(np.int32)
+    b = rng.integers(0, bins, size=n).astype(np.int32)
+    truth[3] = classes          # out of range -> bad
+    b[7] = -1                   # out of range -> bad
+    want = np.zeros((bins, classes, classes), np.int64)
+    for i in range(n):          # cnn.py:242-245 per SNR bin
+        if i not in (3, 7):
+            want[b[i], truth[i], pred[i]] += 1
+    tt, pp, bb = (torch.from_numpy(a).cuda() for a in (truth, pred, b))
+    counts = torch.zeros((bins, classes, classes), dtype=torch.int64, device="cuda")
+    bad = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    _cabi.check(_cabi.lib().mdc_confusion_binned(tt.data_ptr(), pp.data_ptr(), bb.data_ptr(), n, classes, bins, counts.data_ptr(),
+                                                 bad.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    np.testing.assert_array_equal(counts.cpu().numpy(), want)
+    assert int(bad.item()) == 2
+
+
+def test_save_results_writes_the_tuple_the_reference_pickles(tmp_path):
+    """cnn.py:262-264: cPickle.dump(("CNN2", 0.5, acc), fd) -- acc = {snr: accuracy} from the per-SNR loop."""
+    import pickle
+    m = _t1()
+    n = 3000
+    x = synthetic_frames(n, seed=4, device="cuda") * 4.0
+    rng = np.random.default_rng(2)
+    truth = rng.integers(0, 3, size=n)
+    snrs = rng.choice(np.arange(-20, 20, 2), size=n)
+    acc, _ = m.accuracy_by_snr(x, truth, snrs)
+    path = str(tmp_path / "results_cnn2_d0.5.dat")
+    VTCNN2.save_results(path, acc)
+    with open(path, "rb") as fd:
+        tag, dr, got = pickle.load(fd)                      # a file this test just wrote
+    assert (tag, dr) == ("CNN2", 0.5) and got == {int(k): v for k, v in acc.items()}
+    assert all(type(k) is int and type(v) is float for k, v in got.items())
+    assert VTCNN2.load_results(path) == (tag, dr, got)
+    assert open(path, "rb").read(2) == b"\x80\x02"          # protocol 2: readable by the reference's Python-2 cPickle
+
+
+def test_one_process_multi_stream_driver_on_one_gpu():
+    """MultiStreamPredictor (BASELINE configs[3]: per-GPU HIP streams) with G = 1 device and two streams: results equal
+    the single-stream forward, bit for bit, for every topology family."""
+    from modulationdetectioncnn_amd.sharding import MultiStreamPredictor
+    for m, n in ((_t1(), 10001), (VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, device=0, dtype="bf16"), 5000)):
+        msp = MultiStreamPredictor.for_models([m], streams_per_device=2)
+        assert len(msp.lanes) == 2 and msp.lanes[0].stream != msp.lanes[1].stream
+        x = synthetic_frames(n, seed=9, device="cuda")
+        ref_p, ref_l, _ = m.forward_device(x)
+        torch.cuda.synchronize()
+        plan = msp.plan(n)
+        outs = msp.forward_shards([x[lo:hi].contiguous() for _, lo, hi in plan])
+        assert torch.equal(torch.cat([o[0] for o in outs]), ref_p) and torch.equal(torch.cat([o[1] for o in outs]), ref_l)
+        p, l = msp.predict(x.cpu().numpy())
+        np.testing.assert_array_equal(p, ref_p.cpu().numpy())
+        np.testing.assert_array_equal(l, ref_l.cpu().numpy())

@@ -36,6 +36,26 @@ def test_bit_selection_and_wrap_rules():
     assert list(Q.quantize(np.array([0.5, -0.5, -1e-5, 1e-5, 31.9999, -32.0]))) == [2048, -2048, 0, 0, 131071, -131072]
 
 
+def _verilog_select18(a, b, c, d):
+    """signed_mult / signed_mult1 of cnn_test_latest1.sv:642-675 restated on Python integers, independently of the
+    oracle: `wire signed [35:0] mult_out = a*b + c*d` (36-bit wrap), `out = {mult_out[35], mult_out[28:12]}`."""
+    m = (a * b + c * d) & ((1 << 36) - 1)
+    out = (((m >> 35) & 1) << 17) | ((m >> 12) & 0x1FFFF)
+    return out - (1 << 18) if out & (1 << 17) else out
+
+
+def test_select18_takes_its_sign_from_bit_35_of_the_36_bit_wire():
+    lo, hi = -(1 << 17), (1 << 17) - 1
+    corners = [lo, lo + 1, -1, 0, 1, hi - 1, hi]
+    quads = [(a, b, c, d) for a in corners for b in corners for c in corners for d in corners]
+    rng = np.random.default_rng(3)
+    quads += [tuple(int(v) for v in rng.integers(lo, hi + 1, 4)) for _ in range(2000)]
+    for a, b, c, d in quads:
+        assert int(Q.select18(np.array([a * b + c * d]))[0]) == _verilog_select18(a, b, c, d), (a, b, c, d)
+    # the one case where the unwrapped sum's sign differs from bit 35: all four operands -2^17 -> +2^35 -> wraps
+    assert int(Q.select18(np.array([1 << 35]))[0]) == -(1 << 17) == _verilog_select18(lo, lo, lo, lo)
+
+
 def test_matches_recorded_keras_outputs_to_quantisation_error():
     """12.16.testDataYunyun.txt frame 0 is already Q6.12; with the 12.15.latestWeights.txt tables (the SV ROM) the
     integer net must land on Keras' recorded [0, 3.1391976, 0.3649335] within the truncation error."""
@@ -91,6 +111,32 @@ def test_gpu_q612_is_bit_exact(name, n):
     d2, l2 = m.predict_q612(torch.from_numpy(Q.quantize(x).astype(np.int32)), as_float=False)
     np.testing.assert_array_equal(d2.cpu().numpy(), dense)
     np.testing.assert_array_equal(l2.cpu().numpy(), labels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [3, 10])
+def test_gpu_q612_all_operands_at_minus_2_17(F):
+    """a*b + c*d = +2^35 (samples and taps all -32.0 = -2^17) wraps to -2^35 on the 36-bit wire: the conv neuron
+    selects -2^17, the bias -1 wraps the 18-bit sum to +131071, and ReLU lets it through (a sign taken from the
+    unwrapped 64-bit sum would give 0 - 1 -> ReLU 0 instead)."""
+    from modulationdetectioncnn_amd import VTCNN2, Topology
+    rng = np.random.default_rng(11)
+    ck = np.full((1, 2, 1, F), -32.0, np.float32)
+    cb = np.full((F,), -1.0 / 4096.0, np.float32)
+    dk = (rng.integers(-2048, 2048, (258 * F, 3)) / 4096.0).astype(np.float32)
+    db = (rng.integers(-2048, 2048, (3,)) / 4096.0).astype(np.float32)
+    w = [(ck, cb), (dk, db)]
+    x = (rng.standard_normal((70, 2, 128)) * 0.3).astype(np.float32)
+    x[0] = -32.0
+    x[5, 0, :] = -32.0
+    x[9, 1, 40:90] = -32.0
+    ref = Q.forward_from_float(x, w)
+    assert (ref["conv"][0, :, 1:128, :] == 131071).all()          # interior positions of the all -32.0 frame
+    m = VTCNN2(Topology.deployed(F, 3))
+    m.set_weights(w)
+    dense, labels = m.predict_q612(x, as_float=False)
+    np.testing.assert_array_equal(dense.astype(np.int64), ref["dense"])
+    np.testing.assert_array_equal(labels, ref["labels"])
 
 
 @pytest.mark.gpu

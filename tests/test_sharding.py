@@ -85,3 +85,133 @@ def test_gloo_sharded_predict(tmp_path, world, n):
     mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
     els = [float(np.load(tmp_path / f"ok{r}.npy")[0]) for r in range(world)]
     assert max(els) - min(els) < 1e-9            # every rank reports the same MAX
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one process, G lanes (per-GPU HIP streams): slicing, enqueue-all-then-sync-once, concatenation -- with fake lanes
+class _FakeLane:
+    """Records what the driver does to it; computes with the CPU oracle at sync time (like a stream would)."""
+
+    def __init__(self, log, name, weights):
+        self.log, self.name, self.w = log, name, weights
+        self.pending = []
+
+    def upload(self, x):
+        self.log.append(("upload", self.name, len(x)))
+        return np.array(x, np.float32)
+
+    def forward(self, x):
+        self.log.append(("forward", self.name, len(x)))
+        out = {}
+        self.pending.append((x, out))
+        return ("probs", out), ("labels", out)          # placeholders, filled at sync
+
+    def sync(self):
+        from oracle import oracle_np as O
+        self.log.append(("sync", self.name))
+        for x, out in self.pending:
+            out.update(O.forward_deployed(x, *self.w, dtype=np.float32))
+        self.pending = []
+
+    def download(self, t):
+        return t[1][t[0]]
+
+
+@pytest.mark.parametrize("lanes,n", [(1, 10), (2, 1001), (8, 100), (3, 2), (4, 0)])
+def test_multistream_driver_slices_enqueues_then_syncs_once(lanes, n):
+    from modulationdetectioncnn_amd import synthetic_frames
+    from modulationdetectioncnn_amd.sharding import MultiStreamPredictor
+    from oracle import oracle_np as O
+    w = [a for p in load_deployed_npz("3convmodrecnets_CNN2_0.5") for a in p]
+    log = []
+    fl = [_FakeLane(log, g, w) for g in range(lanes)]
+    msp = MultiStreamPredictor(fl, 3)
+    assert [(lo, hi) for _, lo, hi in msp.plan(n)] == shard_bounds(n, lanes)
+    X = synthetic_frames(n, seed=5)
+    p, l = msp.predict(X)
+    ref = O.forward_deployed(X, *w, dtype=np.float32)
+    np.testing.assert_array_equal(l, ref["labels"])
+    np.testing.assert_allclose(p.reshape(-1, 3), ref["probs"].reshape(-1, 3), atol=1e-6)
+    kinds = [e[0] for e in log]
+    # every forward is enqueued before the first sync; exactly one sync per lane
+    assert kinds.index("sync") > max(i for i, k in enumerate(kinds) if k == "forward")
+    assert kinds.count("sync") == lanes and kinds.count("forward") == lanes
+    assert [e[2] for e in log if e[0] == "forward"] == [hi - lo for lo, hi in shard_bounds(n, lanes)]
+    with pytest.raises(ValueError):
+        msp.forward_shards([X] * (lanes + 1))
+
+
+def test_device_is_resolved_once_and_mismatch_is_an_error(monkeypatch):
+    """with device=None the engine, the workspace and the input check must all use the device that was
+    current when the model was built -- not whatever torch.cuda.current_device() says later."""
+    from modulationdetectioncnn_amd import VTCNN2, Topology
+    cur = {"d": 0}
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: cur["d"])
+    m = VTCNN2(Topology.deployed(3, 3))
+    assert m.device_index == 0
+    cur["d"] = 1                              # the caller switches devices after construction
+    assert m.device_index == 0
+    assert VTCNN2(Topology.deployed(3, 3)).device_index == 1
+    assert VTCNN2(Topology.deployed(3, 3), device="cuda:3").device_index == 3
+    assert VTCNN2(Topology.deployed(3, 3), device=2).device_index == 2
+    with pytest.raises(ValueError):
+        VTCNN2(Topology.deployed(3, 3), device="cpu")
+
+    class _T:                                 # a stand-in for a tensor on another GPU: only the checks run
+        is_cuda, dtype, shape = True, torch.float32, (4, 2, 128)
+        device = torch.device("cuda", 1)
+
+        def is_contiguous(self):
+            return True
+    monkeypatch.setattr(torch, "Tensor", _T)
+    with pytest.raises(ValueError, match="cuda:1.*cuda:0"):
+        m.forward_device(_T())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's N>1 control flow under gloo with a stub engine: the JSON line's n_gpus / global_batch / MAX-over-ranks time
+def _bench_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), MDC_BENCH_BACKEND="gloo")
+    import contextlib
+    import io
+    import time
+    import bench
+    from modulationdetectioncnn_amd import Topology
+    from modulationdetectioncnn_amd.sharding import timed_region
+    n = 4096
+
+    class _Stub:
+        topology = Topology.vtcnn2(11)
+        dtype = "bf16"
+
+    def run_workload(name, device, steps, warmup, dist=None):
+        assert dist is not None and dist.get_world_size() == world and device == rank
+        el = timed_region(lambda: time.sleep(0.02 * (rank + 1)), steps, warmup)      # rank 1 is twice as slow
+        return _Stub(), None, None, None, n, el
+
+    bench.run_workload = run_workload
+    bench.select_device = lambda d: None
+    bench.dominant_roofline = lambda *a, **k: ({"bound": "mfma", "frac": 0.0}, {})
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "1", "--no-extras", "--no-cpu-baseline"])
+    with open(os.path.join(out_dir, f"out{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+
+
+def test_bench_main_under_gloo_world2(tmp_path):
+    import json
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "out1.txt").read().strip() == ""           # only rank 0 prints
+    lines = [l for l in open(tmp_path / "out0.txt").read().splitlines() if l.strip()]
+    assert len(lines) == 1                                            # ONE JSON line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["frames_per_gpu"] == 4096 and j["config"]["global_batch"] == 8192
+    assert j["ms_per_step"] >= 40 * 0.9                               # MAX over ranks: the slow rank's 40 ms per step
+    assert abs(j["value"] - 8192 * 4 / (j["ms_per_step"] * 4e-3)) / j["value"] < 1e-6     # whole-job frames / MAX time
+    assert j["metric"].endswith("batch=4096)") and "cpu_baseline" not in j and "extra" not in j
