@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int lp = lane & 31;
     using f32x2 = __attribute__((ext_vector_type(2))) float;
-    constexpr bool kPacked = F >= 8 && !(ABL & 8);
+    constexpr bool kPacked = F >= 8 && !(ABL & 8) && !(ABL & 16);
 
     float k0[F], k1[F], cb[F], bd[kC];
 #pragma unroll
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                 if (TAIL && j >= n) return make_uint2(0u, 0u);
                 return load8_unaligned(pb + (long)j * hop2);
             } else {
+                if (ABL & 32) return (reinterpret_cast<const float4*>(x) + lane)[(long)(j & 15) * 64];      // timing probe: the batch's first 16 frames over and over (cache-resident)
                 if (!TAIL) return px[(long)j * 64];
                 return (j < n) ? px[(long)j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -285,6 +286,29 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                             a2 = __builtin_elementwise_fma(f32x2{wd[2 * pr][ff][2], wd[2 * pr + 1][ff][2]}, y, a2);
                         }
                     s0 = a0.x + a0.y; s1 = a1.x + a1.y; s2 = a2.x + a2.y;
+                } else if constexpr ((ABL & 16) != 0) {
+                    // every instruction independent of the one before it: all filters' first fma, then all second fmas,
+                    // then all ReLUs, then the dense fmas (three accumulator chains in rotation)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float t[F];
+#pragma unroll
+                        for (int ff = 0; ff < F; ++ff) t[ff] = fmaf(k0[ff], xs[s], cb[ff]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ff = 0; ff < F; ++ff) t[ff] = fmaf(k1[ff], xs[s + 1], t[ff]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ff = 0; ff < F; ++ff) t[ff] = fmaxf(t[ff], 0.f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ff = 0; ff < F; ++ff) {
+                            s0 = fmaf(wd[s][ff][0], t[ff], s0);
+                            s1 = fmaf(wd[s][ff][1], t[ff], s1);
+                            s2 = fmaf(wd[s][ff][2], t[ff], s2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -375,6 +399,11 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
 
 }  // namespace
 
+static bool f32_mfma_variant() {
+    const char* e = getenv("MDC_DEP_F32_MFMA");
+    return e && atoi(e) != 0;
+}
+
 // Pack: [F x (k0,k1,b)] [bd x3] pad to 64 floats, then per-lane dense weights
 // wl[((slot*F + f)*3 + c)*64 + lane].
 int deployed_pack(mdc_model* m) {
@@ -400,7 +429,8 @@ int deployed_pack(mdc_model* m) {
                     pk[kHeadFloats + ((size_t)(s * F + f) * kC + c) * 64 + lane] = dk[((size_t)h * 129 * F + (size_t)w * F + f) * kC + c];
         }
     }
-    return upload(m, 0, pk.data(), pk.size() * sizeof(float));
+    const int rc = upload(m, 0, pk.data(), pk.size() * sizeof(float));
+    return rc != MDC_OK ? rc : deployed_f32m_pack(m);      // + the dense layer as f32 MFMA operands (deployed_f32m.hip)
 }
 
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
@@ -414,8 +444,13 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
     const int F = m->topo.filters;
     float* tap_conv = (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) ? tap : nullptr;
     float* tap_dense = (tap_kind == MDC_TAP_DENSE) ? tap : nullptr;
-    const long nfull = tap_conv ? 0 : (n / 64) * 64;      // frames handled by the fast kernel
     ProfScope ps(m, 0, s);
+    // MDC_DEP_F32_MFMA=1 (read per call; A/B measurement and its parity tests) selects the variant with Dense(3) on the
+    // f32 matrix pipe (deployed_f32m.hip: same results to the last bits of the summation order, measured SLOWER --
+    // v_mfma_f32_4x4x1 holds the SIMD's vector issue for its whole 8 cycles); the production f32
+    // path is the all-VALU kernel below.  Conv/flat taps always use the simple one-frame-at-a-time kernel.
+    if (!tap_conv && f32_mfma_variant()) return deployed_f32m_forward(m, x, n, probs, labels, tap_dense, s);
+    const long nfull = tap_conv ? 0 : (n / 64) * 64;      // frames handled by the fast kernel
     if (nfull > 0) {
         long grid = (nfull / 64 + 3) / 4;
         if (grid > 2048) grid = 2048;
@@ -425,6 +460,15 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
         if (abl == 2 && F == 3) { hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); return MDC_OK; }
         if (abl == 3 && F == 3) { hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 3>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); return MDC_OK; }
         if (abl == 7 && F == 3) { hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 7>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); return MDC_OK; }
+#endif
+#ifdef MDC_ABLATIONS   // timing probes of the inner loop: 1 plain fmas in independent phases, 2 the same on cache-resident frames, 3 packed on cache-resident frames
+        static const int phased = getenv("MDC_DEP_PHASED") ? atoi(getenv("MDC_DEP_PHASED")) : 0;
+#define MDC_DEP_PROBE(P, A) if (phased == P && !tap_dense) { \
+            if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, A>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); \
+            else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, A>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense); \
+            MDC_HIP(hipGetLastError()); return MDC_OK; }
+        MDC_DEP_PROBE(1, 16) MDC_DEP_PROBE(2, 48) MDC_DEP_PROBE(3, 32)
+#undef MDC_DEP_PROBE
 #endif
         if (tap_dense) {
             if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
@@ -466,6 +510,7 @@ int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int
     const long hop2 = 2 * (long)hop;
     const float* xb = reinterpret_cast<const float*>(iq);
     ProfScope ps(m, 0, s);
+    if (f32_mfma_variant()) return deployed_f32m_forward_iq_u8(m, iq, n, hop2, scale, probs, labels, s);
     if (nfull > 0) {
         long grid = (nfull / 64 + 3) / 4;
         if (grid > 2048) grid = 2048;

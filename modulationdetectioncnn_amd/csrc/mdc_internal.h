@@ -98,6 +98,10 @@ int upload(mdc_model* m, int idx, const void* host, size_t bytes);
 
 // ---- deployed (T1/T2): deployed.hip -------------------------------------------------
 int deployed_pack(mdc_model* m);
+// f32 with the dense layer on the f32 matrix pipe (production f32 path): deployed_f32m.hip
+int deployed_f32m_pack(mdc_model* m);
+int deployed_f32m_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, float* tap_dense, hipStream_t s);
+int deployed_f32m_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, long hop2, float scale, float* probs, int32_t* labels, hipStream_t s);
 // bf16 mode (dense layer on the matrix cores, lane = frame): deployed_bf16.hip
 int deployed_bf16_pack(mdc_model* m);
 int deployed_bf16_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, hipStream_t s);

@@ -284,3 +284,72 @@ def test_16bit_modes_keep_an_out_of_range_frame_to_itself(dtype):
     np.testing.assert_array_equal(out[keep], clean[keep])
     if dtype == "bf16":          # bf16 has f32's range: a huge frame still classifies (softmax saturates to one class)
         assert np.isfinite(out[5]).all() and abs(out[5].sum() - 1) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The f32 variant with Dense(3) on the f32 matrix pipe (csrc/deployed_f32m.hip, MDC_DEP_F32_MFMA=1): same bar as the
+# production f32 kernel.  It is kept as the measured answer to "can the dense layer leave the VALU at f32?" (DESIGN.md
+# section 4.1c): correct to the same tolerances, slower.
+@pytest.fixture
+def f32_mfma(monkeypatch):
+    monkeypatch.setenv("MDC_DEP_F32_MFMA", "1")       # read by libmdc.so on every call
+
+
+def test_f32_mfma_variant_keras_known_answer_and_bundled_frames(f32_mfma):
+    k = json.load(open(os.path.join(GOLDEN, "keras_kat.json")))
+    x = np.asarray(k["input"], np.float32).reshape(1, 2, 128)
+    m = _model("3convmodrecnets_CNN2_0.5")
+    assert np.abs(m.predict(x, tap="dense")[0] - np.array(k["keras_dense"])).max() < 5e-6
+    assert m.predict_classes(x).tolist() == [0]
+    xb, _ = _frames()
+    for name in H5_NAMES:
+        fz = json.load(open(os.path.join(GOLDEN, "oracle_frozen.json")))["by_weights"][name]
+        mm = _model(name)
+        np.testing.assert_allclose(mm.predict(xb, tap="dense"), np.array(fz["dense"]), rtol=0, atol=5e-6)
+        assert mm.predict_classes(xb).tolist() == fz["labels"]
+
+
+@pytest.mark.parametrize("name", ["3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 63, 64, 65, 1000, 70001])
+def test_f32_mfma_variant_synthetic_parity_and_invariances(f32_mfma, name, n):
+    x = synthetic_frames(n, seed=2016)
+    w = [a for p in load_deployed_npz(name) for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)
+    m = _model(name)
+    scale = max(1.0, float(np.abs(ref["dense"]).max()))
+    np.testing.assert_allclose(m.predict(x, tap="dense"), ref["dense"], rtol=0, atol=2e-6 * scale)
+    p = m.predict(x)
+    np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
+    lab = m.predict_classes(x)
+    assert _check_labels(lab, ref) <= max(1, n // 20000)
+    assert (lab == np.argmax(p, axis=1)).all()
+    if n >= 63:
+        # chunking and permutation leave every bit alone (runs of 1..16 four-frame groups, any position in a group)
+        xt = torch.from_numpy(x).cuda()
+        pt = m.predict(xt)
+        for bs in (1, 5, 64, 997):
+            if bs == 1 and n > 2000:
+                continue
+            assert torch.equal(pt, m.predict(xt, batch_size=bs))
+        perm = torch.randperm(n, device="cuda")
+        assert torch.equal(m.predict(xt[perm].contiguous()), pt[perm])
+
+
+def test_f32_mfma_variant_raw_bytes_and_nonfinite_isolation(f32_mfma):
+    from modulationdetectioncnn_amd import frames_from_iq_u8
+    for name in ("3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"):
+        m = _model(name)
+        for hop, n in ((128, 4097), (3, 1000), (1, 65)):
+            iq = torch.from_numpy(np.random.default_rng(hop).integers(0, 256, size=2 * (128 + hop * (n - 1)), dtype=np.uint8)).cuda()
+            p, l = m.predict_iq_u8(iq, 0.02 / 127.5, hop=hop)
+            p2, l2, _ = m.forward_device(frames_from_iq_u8(iq, 0.02 / 127.5, hop=hop))
+            assert torch.equal(p, p2) and torch.equal(l, l2), (name, hop)
+        x = synthetic_frames(4096, seed=5, device="cuda")
+        base = m.predict(x)
+        xb = x.clone()
+        bad = torch.tensor([1, 2, 7, 64, 4000], device="cuda")
+        xb[bad, 0, 5] = float("inf")
+        xb[bad[::2], 1, 127] = float("nan")
+        keep = torch.ones(4096, dtype=torch.bool, device="cuda")
+        keep[bad] = False
+        assert torch.equal(m.predict(xb)[keep], base[keep])
