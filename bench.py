@@ -321,6 +321,13 @@ def main(argv=None):
                     torch.cuda.empty_cache()
                 except Exception as e:
                     extras.append({"workload": f"deployed{filters}-iq-u8-n2^22", "error": repr(e)})
+            try:      # one window at a time, as the reference's deployment runs (tools/latency.py)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import latency
+                extras.append({"workload": "latency: one forward call, frames resident in HBM, enqueue -> result on the device, median of 100",
+                               "unit": "us", "rows": latency.rows(device, sizes=(1, 16, 64, 4096), reps=100)})
+            except Exception as e:
+                extras.append({"workload": "latency", "error": repr(e)})
             out["extra"] = extras
     if dist:
         dist.barrier()

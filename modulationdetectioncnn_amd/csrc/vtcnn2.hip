@@ -45,8 +45,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // position block (11 outputs) x 16-channel chunk (conv2 weights of the chunk, 30 KB, staged
 // in LDS and shared by the 4 waves) x 13 padded positions x 2 rows x [1 conv1 + 60 conv2 MFMAs].
 // ------------------------------------------------------------------------------------
-constexpr int kP = 11;                 // output positions per block
-constexpr int kNPB = kW2 / kP;         // 12 blocks
+constexpr int kP = 11;                 // output positions per block (batch form; the small-batch forms use 3 and 1)
 constexpr int kChunk = 16;             // channels per chunk
 constexpr int kNChunk = kC1 / kChunk;  // 16
 constexpr int kWChunkFloats = 2 * 3 * 5 * 4 * 64;   // [h][j][ot][r][lane] = 7680
@@ -56,7 +55,13 @@ constexpr size_t kConvF32Lds = (2 * kWChunkFloats + kXinFloats) * sizeof(float);
 
 // U8 = true (mdc_forward_iq_u8): x points at raw interleaved uint8 (I,Q) pairs, window f at byte f*hop2; a lane loads
 // the 8 bytes holding its four samples of both rows and converts its row with iq_u8_kernel's arithmetic (eval_ops.hip).
-template <bool U8>
+// KP = output positions per block (register blocking: 5*KP accumulator tiles), YSPLIT = one position block per
+// work-group (blockIdx.y) instead of a loop over the 132/KP blocks.  Every form runs the SAME instruction sequence per
+// output element (chunk order, tap order, fma chain), so the results are bit-identical; what changes is how many
+// work-groups share a frame group.  A single window (the reference classifies one window per start pulse,
+// cnn_test_latest1.sv:144-209) with KP = 11 and no split streams all of conv2 through ONE CU (4.8 ms); KP = 1 with
+// the split spreads its 132 positions over 132 CUs.
+template <bool U8, int KP, bool YSPLIT>
 __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __restrict__ x, long n,
                                                              const float* __restrict__ wpack,   // [16 chunks][7680]
                                                              const float* __restrict__ a1pack,  // [16 chunks][64 lanes]
@@ -104,11 +109,13 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
     const float* xrow1 = xw + (1 * 16 + nl) * kXld + g;
 
     int it = 0;
-    for (int pb = 0; pb < kNPB; ++pb) {
-        const int w0 = pb * kP;
-        f32x4 acc[kP][5];
+    constexpr int kNPB = kW2 / KP;
+    static_assert(kNPB * KP == kW2, "KP must divide 132");
+    for (int pb = YSPLIT ? (int)blockIdx.y : 0; pb < (YSPLIT ? (int)blockIdx.y + 1 : kNPB); ++pb) {
+        const int w0 = pb * KP;
+        f32x4 acc[KP][5];
 #pragma unroll
-        for (int a = 0; a < kP; ++a)
+        for (int a = 0; a < KP; ++a)
 #pragma unroll
             for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
             }
             const float a1 = a1pack[cc * 64 + lane];   // conv1 A operand: K1[c][g] (g<3) | b1[c] (g=3)
 #pragma unroll
-            for (int u = 0; u < kP + 2; ++u) {
+            for (int u = 0; u < KP + 2; ++u) {
                 const int wp = w0 + u;                 // padded position w' of y1p
                 if (wp < 2 || wp > 131) continue;      // zero padding of y1p: contributes nothing
                 const int v = wp - 2;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int wo = u - j;          // local output position: w = w' - j
-                        if (wo < 0 || wo >= kP) continue;
+                        if (wo < 0 || wo >= KP) continue;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
         const long f = frame0 + nl;
         if (f < n) {
 #pragma unroll
-            for (int a = 0; a < kP; ++a)
+            for (int a = 0; a < KP; ++a)
 #pragma unroll
                 for (int ot = 0; ot < 5; ++ot) {
                     const int o = ot * 16 + g * 4;
@@ -243,6 +250,42 @@ __global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restr
                 if (row < n) hid[row * kHid + col] = fmaxf(acc[i][j][r] + bias, 0.f);
             }
         }
+}
+
+// Small batches: one wave = a 16-frame x 16-unit tile over the whole K, both operands straight from global memory in the
+// MFMA's lane order (A[row = lane&15][k = kk + (lane>>4)], B[k][col = lane&15], as the tiled kernel reads them from LDS):
+// the same instruction and the same K order per output element, so the results are bit-identical, on 16 x ceil(n/16)
+// CUs instead of one or two.
+__global__ __launch_bounds__(64) void vt_dense1_f32_small_kernel(const float* __restrict__ feat, long n,
+                                                                 const float* __restrict__ w1p,   // [10560][256]
+                                                                 const float* __restrict__ c1, float* __restrict__ hid) {
+    const int lane = threadIdx.x, fr = lane & 15, fq = lane >> 4;
+    const long row0 = (long)blockIdx.x * 16;
+    const int col0 = blockIdx.y * 16;
+    long ar = row0 + fr;
+    if (ar >= n) ar = n - 1;                                  // rows past the end are computed, not stored
+    const float* ap = feat + ar * (long)kFeat + fq;
+    const float* bp = w1p + (size_t)fq * kHid + col0 + fr;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kU = 16;                                    // MFMAs (k-steps of 4) per iteration: 32 loads in flight
+    static_assert(kFeat % (4 * kU) == 0, "unroll must divide K / 4");
+    for (int k0 = 0; k0 < kFeat; k0 += 4 * kU) {
+        float a[kU], b[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            a[u] = ap[k0 + 4 * u];
+            b[u] = bp[(size_t)(k0 + 4 * u) * kHid];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    const int col = col0 + fr;
+    const float bias = c1[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long row = row0 + fq * 4 + r;
+        if (row < n) hid[row * kHid + col] = fmaxf(acc[r] + bias, 0.f);
+    }
 }
 
 // feat[f][w][o] (f32 or bf16) -> reference layout (80,132) channels_first, f32   ('conv'/'flat' taps)
@@ -348,25 +391,39 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
     } else {
         {
             ProfScope ps(m, 0, s);
-            // per launch, like every other kernel here: the attribute is per DEVICE, and one process may drive several
+            // per launch, like every other kernel here: the attribute is per DEVICE, and one process may drive several.
+            // Form by batch size (results identical): up to 64 frames one position per work-group (132 CUs per frame
+            // group), up to 384 three, up to 2,048 the batch blocking with one block per work-group, else the loop.
+            const unsigned groups = (unsigned)((n + 63) / 64);
+#define MDC_LAUNCH_CONV_F32(U, KP, YS) do { \
+                MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel<U, KP, YS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds)); \
+                hipLaunchKernelGGL((vt_conv_f32_kernel<U, KP, YS>), dim3(groups, YS ? kW2 / KP : 1), dim3(256), kConvF32Lds, s, x, (long)n, \
+                                   static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]), \
+                                   static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat), hop2 > 0 ? hop2 : 256L, scale); } while (0)
             if (hop2 > 0) {
-                MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds));
-                hipLaunchKernelGGL(vt_conv_f32_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), kConvF32Lds, s, x, (long)n,
-                                   static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]),
-                                   static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat), hop2, scale);
+                if (n <= 64) MDC_LAUNCH_CONV_F32(true, 1, true);
+                else if (n <= 384) MDC_LAUNCH_CONV_F32(true, 3, true);
+                else if (n <= 2048) MDC_LAUNCH_CONV_F32(true, 11, true);
+                else MDC_LAUNCH_CONV_F32(true, 11, false);
             } else {
-                MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds));
-                hipLaunchKernelGGL(vt_conv_f32_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), kConvF32Lds, s, x, (long)n,
-                                   static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]),
-                                   static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat), 256L, 0.f);
+                if (n <= 64) MDC_LAUNCH_CONV_F32(false, 1, true);
+                else if (n <= 384) MDC_LAUNCH_CONV_F32(false, 3, true);
+                else if (n <= 2048) MDC_LAUNCH_CONV_F32(false, 11, true);
+                else MDC_LAUNCH_CONV_F32(false, 11, false);
             }
+#undef MDC_LAUNCH_CONV_F32
             MDC_HIP(hipGetLastError());
         }
         {
             ProfScope ps(m, 1, s);
-            hipLaunchKernelGGL(vt_dense1_f32_kernel, dim3((unsigned)((n + kDM - 1) / kDM), kHid / kDN), dim3(256), 0, s,
-                               static_cast<const float*>(feat), (long)n, static_cast<const float*>(m->d_pack[3]),
-                               static_cast<const float*>(m->d_pack[4]), hid);
+            if (n <= 64)
+                hipLaunchKernelGGL(vt_dense1_f32_small_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s,
+                                   static_cast<const float*>(feat), (long)n, static_cast<const float*>(m->d_pack[3]),
+                                   static_cast<const float*>(m->d_pack[4]), hid);
+            else
+                hipLaunchKernelGGL(vt_dense1_f32_kernel, dim3((unsigned)((n + kDM - 1) / kDM), kHid / kDN), dim3(256), 0, s,
+                                   static_cast<const float*>(feat), (long)n, static_cast<const float*>(m->d_pack[3]),
+                                   static_cast<const float*>(m->d_pack[4]), hid);
             MDC_HIP(hipGetLastError());
         }
     }

@@ -291,9 +291,61 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Small batches (a single window, or a few): the 256-row tile above would run its 165 K-tiles on ONE CU with 1/16 or
+// less of its rows in use.  Here one wave owns a 16-frame x 16-unit tile over the whole K and takes both operands
+// straight from global memory in MFMA fragment order (16 B per lane per operand per MFMA; the weights stay in L2), so
+// 16 x ceil(n/16) waves on as many CUs share the layer.  Same instruction (v_mfma_f32_16x16x32_bf16), same fragment
+// contents and the same K order per output element as the tiled kernels: bit-identical results.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vt_dense1_bf16_small_kernel(const unsigned short* __restrict__ feat, long n,
+                                                                  const unsigned short* __restrict__ w1t,   // [165 k-tiles][256][64] bf16
+                                                                  const float* __restrict__ c1, float* __restrict__ hid) {
+    const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+    const long row0 = (long)blockIdx.x * 16;
+    const int col0 = blockIdx.y * 16;
+    long ar = row0 + fr;
+    if (ar >= n) ar = n - 1;                                  // rows past the end are computed, not stored
+    const unsigned short* ap = feat + ar * (long)kFeat + fg * 8;
+    const unsigned short* bp = w1t + (long)(col0 + fr) * kBK + fg * 8;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kU = 5;                                     // K-tiles per iteration: 20 fragment loads in flight
+    static_assert(kNT % kU == 0, "unroll must divide the K-tile count");
+    for (int t0 = 0; t0 < kNT; t0 += kU) {
+        bf16x8 af[kU][2], bfr[kU][2];
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                af[u][ks] = *reinterpret_cast<const bf16x8*>(ap + (t0 + u) * kBK + ks * 32);
+                bfr[u][ks] = *reinterpret_cast<const bf16x8*>(bp + (long)(t0 + u) * (kBN * kBK) + ks * 32);
+            }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][ks], bfr[u][ks], acc, 0, 0, 0);
+    }
+    const int col = col0 + fr;
+    const float bias = c1[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long row = row0 + fg * 4 + r;
+        if (row < n) hid[row * kHid + col] = fmaxf(acc[r] + bias, 0.f);
+    }
+}
+
+constexpr long kSmallBatch = 64;       // frames up to which the per-wave kernel is used
+
 }  // namespace
 
 int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s) {
+    if (n <= kSmallBatch) {
+        hipLaunchKernelGGL(vt_dense1_bf16_small_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s,
+                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
+                           static_cast<const float*>(m->d_pack[4]), hid);
+        MDC_HIP(hipGetLastError());
+        return MDC_OK;
+    }
 #define MDC_LAUNCH_D1(A) do { \
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds)); \
     hipLaunchKernelGGL(vt_dense1_bf16_kernel<A>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s, \

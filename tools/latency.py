@@ -1,24 +1,40 @@
 #!/usr/bin/env python3
-"""Small-batch latency (the reference's deployment classifies one window at a time): wall time of one forward call,
-enqueue to result-on-device, for n = 1 .. 4096 frames already resident in HBM; median of 200 calls."""
-import os, sys, time, statistics, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames
+"""Small-batch latency (the reference's deployment classifies ONE window per start pulse, cnn_test_latest1.sv:144-209):
+wall time of one forward call, enqueue to result-on-device, for n = 1 .. 4096 frames already resident in HBM; median of
+`reps` calls.  `rows()` is what bench.py reports as its "latency" extra leg."""
+import os, sys, time, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
-for name, make in (("T1 f32", lambda: VTCNN2.synthetic("deployed3", device=0)),
-                   ("T2 f32", lambda: VTCNN2.synthetic("deployed10", device=0)),
-                   ("T2 bf16", lambda: VTCNN2.synthetic("deployed10", device=0, dtype="bf16")),
-                   ("T3 bf16", lambda: VTCNN2.synthetic(Topology.vtcnn2(11), device=0, dtype="bf16")),
-                   ("T3 f32", lambda: VTCNN2.synthetic(Topology.vtcnn2(11), device=0, dtype="f32"))):
-    m = make()
-    row = []
-    for n in (1, 16, 256, 4096):
-        x = synthetic_frames(n, seed=1, device="cuda:0")
-        probs = torch.empty((n, m.topology.classes), dtype=torch.float32, device="cuda"); labels = torch.empty((n,), dtype=torch.int32, device="cuda")
-        for _ in range(20): m.forward_device(x, probs, labels)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(200):
-            t = time.perf_counter(); m.forward_device(x, probs, labels); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-        row.append(f"n={n}: {statistics.median(ts)*1e6:.0f} us")
-    print(f"{name}: " + ", ".join(row), flush=True)
+MODELS = (("T1 f32", "deployed3", "f32"), ("T2 f32", "deployed10", "f32"), ("T2 bf16", "deployed10", "bf16"),
+          ("T3 f32", "vtcnn2", "f32"), ("T3 bf16", "vtcnn2", "bf16"), ("T3 fp8", "vtcnn2", "fp8"))
+
+
+def rows(device=0, sizes=(1, 16, 64, 256, 4096), reps=200, models=MODELS):
+    import torch
+    from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames
+    out = []
+    for name, topo, dtype in models:
+        m = VTCNN2.synthetic(Topology.vtcnn2(11) if topo == "vtcnn2" else topo, device=device, dtype=dtype)
+        us = {}
+        for n in sizes:
+            x = synthetic_frames(n, seed=1, device=f"cuda:{device}")
+            probs = torch.empty((n, m.topology.classes), dtype=torch.float32, device=x.device)
+            labels = torch.empty((n,), dtype=torch.int32, device=x.device)
+            for _ in range(20):
+                m.forward_device(x, probs, labels)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                m.forward_device(x, probs, labels)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t)
+            us[str(n)] = round(statistics.median(ts) * 1e6, 1)
+        out.append({"model": name, "median_us_by_frames": us})
+    return out
+
+
+if __name__ == "__main__":
+    for r in rows():
+        print(f"{r['model']}: " + ", ".join(f"n={k}: {v:.0f} us" for k, v in r["median_us_by_frames"].items()), flush=True)
