@@ -32,6 +32,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0                                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}  # dense MFMA peaks (no sparsity)
+PEAK_VALU_F32_TFLOPS = 157.3                                 # same guide: vector f32 peak (= the f32 matrix rate)
+# deployed legs whose bounding roof is the f32 vector ALU, not HBM (the 10-filter net at every dtype's
+# conv, the 3-filter net once its input is 256 B of raw bytes): they report bound = "valu" with the HBM fraction beside it
+VALU_BOUND = {("deployed", 10, "f32", "frames"), ("deployed", 10, "f32", "u8"), ("deployed", 3, "f32", "u8"),
+              ("deployed", 10, "bf16", "frames"), ("deployed", 10, "f16", "frames")}
 
 WORKLOADS = {
     # name: (topology kind, filters, classes, dtype, per-GPU frames, weights)
@@ -105,14 +110,24 @@ def dominant_roofline(m, x, probs, labels, steps):
               "frac": ach / peak, "traffic": measured_traffic(f"{name}/{m.dtype}", frames_per_launch),
               "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
     else:
-        by = topo.io_bytes_per_frame * frames_per_launch
-        ach = by / (avg_ms * 1e-3) / 1e9
-        rl = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": ach / PEAK_HBM_GBS,
-              "traffic": measured_traffic((f"{name}/F{topo.filters}" + ("/" + m.dtype if m.dtype != "f32" else "")) if topo.kind == "deployed" else name,
-                                          frames_per_launch),
-              "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
+        rl = deployed_roofline(topo, m.dtype, name, avg_ms, frames_per_launch, "frames")
     return rl, kernels
+
+
+def deployed_roofline(topo, dtype, name, avg_ms, frames_per_launch, source):
+    """HBM roofline on the algorithmic bytes (1,024 B of f32 frame -- or 256 B of raw uint8 I/Q -- in, 4C out), or, for
+    the legs DESIGN.md calls VALU-bound, the f32 vector roofline on the algorithmic FLOPs with the HBM fraction beside it."""
+    by = (topo.io_bytes_per_frame if source == "frames" else 256 + 4 * topo.classes) * frames_per_launch
+    gbs = by / (avg_ms * 1e-3) / 1e9
+    key = (f"{name}/F{topo.filters}" + ("/" + dtype if dtype != "f32" else "") + ("/u8" if source == "u8" else "")) if topo.kind == "deployed" else name
+    traffic = measured_traffic(key, frames_per_launch)
+    if (topo.kind, topo.filters, dtype, source) in VALU_BOUND:
+        tf = topo.flops_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e12
+        return {"bound": "valu", "kernel": name, "achieved": tf, "peak": PEAK_VALU_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / PEAK_VALU_F32_TFLOPS, "traffic": traffic, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
+                "hbm_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
+    return {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "traffic": traffic, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
 
 
 def usable_cpus():
@@ -210,8 +225,9 @@ def run_workload(name, device, steps, warmup, dist=None):
 
 def run_iq_u8(filters, device, steps=20, warmup=5, n=1 << 22):
     """Extra leg: raw RTL-SDR bytes (256 B/frame) straight into a deployed net (mdc_forward_iq_u8)
-    with the two-pass path (mdc_iq_u8_to_frames + mdc_forward) beside it.  HBM roofline on the algorithmic bytes
-    (256 in + 12 probabilities + 4 label out), from the wall time of the timed region (one launch per step)."""
+    with the two-pass path (mdc_iq_u8_windows + mdc_forward) beside it.  Roofline from the kernel's own launch time
+    (HIP events inside the library, untimed extra pass) on the algorithmic bytes (256 in + 12 out) or, where the leg is
+    VALU-bound, on its FLOPs."""
     import torch
     from modulationdetectioncnn_amd import frames_from_iq_u8
     from modulationdetectioncnn_amd.sharding import timed_region
@@ -219,6 +235,12 @@ def run_iq_u8(filters, device, steps=20, warmup=5, n=1 << 22):
     iq = torch.randint(0, 256, (n * 256,), dtype=torch.uint8, device=f"cuda:{device}")
     scale = 0.02 / 127.5
     el = timed_region(lambda: m.predict_iq_u8(iq, scale), steps, warmup, sync=torch.cuda.synchronize, device=iq.device)
+    m.set_profiling(True)
+    for _ in range(5):
+        m.predict_iq_u8(iq, scale)
+    torch.cuda.synchronize()
+    (kname, (kms, kcnt)), = m.read_profile().items()
+    m.set_profiling(False)
     probs = torch.empty((n, 3), dtype=torch.float32, device=iq.device)
     labels = torch.empty((n,), dtype=torch.int32, device=iq.device)
     el2 = timed_region(lambda: m.forward_device(frames_from_iq_u8(iq, scale), probs=probs, labels=labels), steps, warmup,
@@ -228,12 +250,33 @@ def run_iq_u8(filters, device, steps=20, warmup=5, n=1 << 22):
     g = os.path.join(ROOT, "tests", "golden", "weights")
     mh = VTCNN2.from_npz(os.path.join(g, "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"), device=device, dtype="f16")
     elh = timed_region(lambda: mh.predict_iq_u8(iq, scale), steps, warmup, sync=torch.cuda.synchronize, device=iq.device)
-    gbs = (256 + 16) * n * steps / el / 1e9
+    # sliding windows over one capture (hop 16 pairs = 32 new bytes per window): the live-stream form of README.md:5
+    hop = 16
+    nw = (n * 128 - 128) // hop + 1
+    nw = min(nw, 1 << 22)
+    elw = timed_region(lambda: m.predict_iq_u8(iq[: 2 * (128 + hop * (nw - 1))], scale, hop=hop), 5, 2, sync=torch.cuda.synchronize, device=iq.device)
     return {"workload": f"deployed{filters}-iq-u8-n2^22", "value": n * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
             "dtype": "f32", "input": "uint8 interleaved I/Q, 256 B/frame, resident in HBM",
             "two_pass_value": n * steps / el2, "f16_mode_value": n * steps / elh,
-            "roofline": {"bound": "hbm", "kernel": "mdc_deployed_fwd (raw-IQ form)", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                         "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "from": "wall time, one launch per step"}}
+            "sliding_windows_hop16_value": nw * 5 / elw,
+            "roofline": deployed_roofline(m.topology, "f32", kname, kms / kcnt, n, "u8")}
+
+
+def run_q612(filters, device, steps=10, warmup=3, n=1 << 20):
+    """Extra leg: the FPGA's Q6.12 integer forward (mdc_forward_q612) on float frames resident in HBM.
+    Algorithmic bytes: 1,024 in + 12 (class sums) + 4 (label) out per frame; the kernel is integer-VALU-bound (18 x 18
+    bit products in 64-bit arithmetic), so the HBM fraction is a report, not its roof."""
+    import torch
+    from modulationdetectioncnn_amd import synthetic_frames
+    from modulationdetectioncnn_amd.sharding import timed_region
+    m, _, _ = make_model("deployed3-f32-n2^20" if filters == 3 else "deployed10-f32-n2^20", device)
+    x = synthetic_frames(n, seed=2016, sigma=0.3, device=f"cuda:{device}")
+    el = timed_region(lambda: m.predict_q612(x, as_float=False), steps, warmup, sync=torch.cuda.synchronize, device=x.device)
+    gbs = (1024 + 16) * n * steps / el / 1e9
+    return {"workload": f"deployed{filters}-q612-n2^20", "value": n * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
+            "dtype": "int18/int32 (Q6.12)", "roofline": {"bound": "int-valu", "kernel": "mdc_deployed_q612", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                                        "from": "wall time incl. two small output allocations, one launch per step; HBM fraction reported, the bound is 64-bit integer VALU"}}
 
 
 def metric_name(kind, filters, n):
@@ -321,6 +364,11 @@ def main(argv=None):
                     torch.cuda.empty_cache()
                 except Exception as e:
                     extras.append({"workload": f"deployed{filters}-iq-u8-n2^22", "error": repr(e)})
+                try:
+                    extras.append(run_q612(filters, device))
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    extras.append({"workload": f"deployed{filters}-q612-n2^20", "error": repr(e)})
             try:      # one window at a time, as the reference's deployment runs (tools/latency.py)
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import latency

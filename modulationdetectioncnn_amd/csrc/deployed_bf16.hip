@@ -47,7 +47,12 @@ struct Bf16Geom {
     static constexpr int kExtraMfma = (2 * F + 7) / 8;                // position w = 0 of both rows
     static constexpr int kMfma = kMainMfma + kExtraMfma;
     static constexpr int kATabBytes = kMfma * 4 * kC * 16;            // A table, rows 0..2 only: [mfma][kg][class][8 bf16]
-    static constexpr int kPairStride = 1024 + 16;                     // one DMA instruction: row r of two frames (2 x 512 B) + pad
+    static constexpr int kPairStride = 1024 + 32;                     // one DMA instruction: row r of frames i and i+8 (2 x 512 B) + pad.
+                                                                      // Pairing (f, f+8) and a stride of 264 words puts the 16 lanes one
+                                                                      // ds_read_b128 cycle serves -- f in {0..3, 12..15} of k-group g and
+                                                                      // f in {4..11} of g+1 -- on 16 different 4-bank groups (pairing
+                                                                      // (f, f+1) at 260 words ran every piece read 2-way conflicted:
+                                                                      // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.40-0.62, profiles/r02)
     static constexpr int kStageBytes = 8 * kPairStride;               // ONE ROW of a 16-frame group
     static constexpr int kWaves = 8;                                  // 2 per SIMD, each with TWO row buffers (8, 12, 16 waves with
                                                                       // one buffer: 3.45 / 3.40 / 3.06e9 frames/s for F = 10)
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* stage = smem + G::kATabBytes + wv * 2 * G::kStageBytes;      // row r of a group goes to buffer r
     // piece 4jj + g (jj = 0..7) of the staged row r of frame f at mine0 + r * kStageBytes + 64 jj
-    const unsigned char* mine0 = stage + (f >> 1) * G::kPairStride + (f & 1) * 512 + g * 16;
+    const unsigned char* mine0 = stage + (f & 7) * G::kPairStride + (f >> 3) * 512 + g * 16;
     // this lane's A row: class c = lane & 15, k-group g.  Rows 3..15 of the MFMA are never read back, so their
     // lanes simply load class 0's weights again (no zero rows in LDS, no masking)
     const uint4* a_mine = a_lds + g * kC + (f < kC ? f : 0);
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
     auto stage_row = [&](long grp, int r) {       // 8 x (2 x 512 B); frames past the end of the batch re-read the last one
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const long fr = grp * 16 + 2 * i + (lane >> 5);
+            const long fr = grp * 16 + i + 8 * (lane >> 5);
             glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + r * kSamples + (lane & 31) * 4, stage + r * G::kStageBytes + i * G::kPairStride);
         }
     };

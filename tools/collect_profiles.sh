@@ -1,15 +1,18 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root: collects the rocprofv3 data behind profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh'
-# then, back in the container:  python tools/summarize_profiles.py r01
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'
+# then, back in the container:  python tools/summarize_profiles.py r02 ; python tools/summarize_dep_counters.py r02
 # Kernel timing and PMC counters are separate runs (gpurun refuses --pmc combined with API traces), and
-# FETCH_SIZE / WRITE_SIZE are separate passes as MI355X_MICROARCH.md prescribes.
+# FETCH_SIZE / WRITE_SIZE are separate passes as MI355X_MICROARCH.md prescribes.  Directory names carry no round tag
+# (gpurun_out/ is scratch): summarize_profiles.py stamps the round on what it copies into profiles/.
 set -e -o pipefail
 R=$PWD
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 P="--output-format csv"
-if [ "$1" != "dep" ]; then
-rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_r01_bench -- python3 $R/bench.py --steps 10 --warmup 3 > $R/gpurun_out/prof_r01_bench.log 2>&1
+rm -rf $R/gpurun_out/prof_${TAG}_bench $R/gpurun_out/pmc_*_vt $R/gpurun_out/pmc_*_dep $R/gpurun_out/prof_${TAG}_dep
+if [ "$2" != "dep" ]; then
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench -- python3 $R/bench.py --steps 10 --warmup 3 > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
 echo "kernel stats done"
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt -- $B > $R/gpurun_out/pmc_fetch_vt.log 2>&1
@@ -18,8 +21,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES $P -d $R/gpurun_out/pmc_lds_vt -- $B > $R/gpurun_out/pmc_lds_vt.log 2>&1
 echo "vtcnn2 counters done"
 fi
-D="python3 $R/tools/prof_deployed.py"
-rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_r01_dep -- $D > $R/gpurun_out/prof_r01_dep.log 2>&1
+D="python3 $R/tools/prof_deployed.py f32 bf16 f16 u8"
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_dep -- $D > $R/gpurun_out/prof_${TAG}_dep.log 2>&1
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_dep -- $D > $R/gpurun_out/pmc_fetch_dep.log 2>&1
 rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_dep -- $D > $R/gpurun_out/pmc_write_dep.log 2>&1
 echo "deployed done"

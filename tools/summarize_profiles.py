@@ -43,14 +43,23 @@ spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in th
     ("mdc_vt_conv/bf16", "vt", "vt_conv_bf16", 65536),
     ("mdc_vt_dense1/bf16", "vt", "vt_dense1_bf16", 65536),
     ("mdc_vt_head", "vt", "vt_head_kernel", 65536),
-    ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3", 1 << 20),
-    ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10", 1 << 20),
+    ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3, 0, 0, false, false>", 1 << 20),
+    ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10, 0, 0, false, false>", 1 << 20),
     ("mdc_deployed_fwd/F3/bf16", "dep", "deployed_bf16_kernel<3, false, false>", 1 << 20),
     ("mdc_deployed_fwd/F10/bf16", "dep", "deployed_bf16_kernel<10, false, false>", 1 << 20),
     ("mdc_deployed_fwd/F3/f16", "dep", "deployed_bf16_kernel<3, true, false>", 1 << 20),
     ("mdc_deployed_fwd/F10/f16", "dep", "deployed_bf16_kernel<10, true, false>", 1 << 20),
+    # raw uint8 I/Q input (256 B/frame): the U8 = true forms of the same kernels
+    ("mdc_deployed_fwd/F3/u8", "dep", "deployed_fwd_kernel<3, 0, 0, false, true>", 1 << 20),
+    ("mdc_deployed_fwd/F10/u8", "dep", "deployed_fwd_kernel<10, 0, 0, false, true>", 1 << 20),
+    ("mdc_deployed_fwd/F3/bf16/u8", "dep", "deployed_bf16_kernel<3, false, true>", 1 << 20),
+    ("mdc_deployed_fwd/F10/bf16/u8", "dep", "deployed_bf16_kernel<10, false, true>", 1 << 20),
+    ("mdc_deployed_fwd/F3/f16/u8", "dep", "deployed_bf16_kernel<3, true, true>", 1 << 20),
+    ("mdc_deployed_fwd/F10/f16/u8", "dep", "deployed_bf16_kernel<10, true, true>", 1 << 20),
 ]
-out = {"note": "bytes per launch; FETCH_SIZE doubled (gfx950 wide-read correction), KiB -> bytes", "kernels": {}}
+out = {"note": "bytes per launch; FETCH_SIZE doubled (gfx950 wide-read correction: calibrated for 16 B/lane streaming reads; the /u8 "
+               "kernels read 8 B per lane or 16 B per LDS-DMA lane, so their read side is the guide's 'uncalibrated width' case -- the "
+               "raw counter is kept beside it), KiB -> bytes", "kernels": {}}
 for key, sfx, kern, frames in spec:
     fe = counters("pmc_fetch_" + sfx, kern).get("FETCH_SIZE")
     wr = counters("pmc_write_" + sfx, kern).get("WRITE_SIZE")
