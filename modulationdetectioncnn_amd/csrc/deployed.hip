@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
         };
 #pragma unroll
         for (int f = 0; f < 4; ++f) cur_raw[f] = load(f);
-        for (int G = 0; G < 16; ++G) {
+        // a ragged block stops after its last group with a real frame: a single window (n = 1, the reference's
+        // deployment) then costs one group, not sixteen; a frame's arithmetic does not depend on what follows it
+        const int ngrp = TAIL ? (int)((n + 3) >> 2) : 16;
+        for (int G = 0; G < ngrp; ++G) {
             // prefetch the next group (the last group re-reads itself: harmless, stays in bounds).  One group
             // ahead is the measured optimum; two groups ahead (12 KB per wave in flight) was 10 % slower.
             const int Gn = (G < 15) ? G + 1 : 15;

@@ -267,17 +267,30 @@ __global__ __launch_bounds__(64) void vt_dense1_f32_small_kernel(const float* __
     const float* ap = feat + ar * (long)kFeat + fq;
     const float* bp = w1p + (size_t)fq * kHid + col0 + fr;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int kU = 16;                                    // MFMAs (k-steps of 4) per iteration: 32 loads in flight
-    static_assert(kFeat % (4 * kU) == 0, "unroll must divide K / 4");
-    for (int k0 = 0; k0 < kFeat; k0 += 4 * kU) {
-        float a[kU], b[kU];
+    // software pipeline: the operands of the next kU k-steps are in flight while this block's MFMAs (one dependent
+    // chain: the K order is the result) run -- loading and multiplying in turns took 114-307 us per launch, K = 10,560
+    constexpr int kU = 24;                                    // MFMAs (k-steps of 4) per block: 48 loads in flight
+    constexpr int kBlocks = kFeat / (4 * kU);
+    static_assert(kBlocks * 4 * kU == kFeat, "block size must divide K / 4");
+    float a[2][kU], b[2][kU];
+    auto fetch = [&](int blk, float (&aa)[kU], float (&bb)[kU]) {
+        const int k0 = blk * 4 * kU;
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            a[u] = ap[k0 + 4 * u];
-            b[u] = bp[(size_t)(k0 + 4 * u) * kHid];
+            aa[u] = ap[k0 + 4 * u];
+            bb[u] = bp[(size_t)(k0 + 4 * u) * kHid];
         }
+    };
+    fetch(0, a[0], b[0]);
+    for (int blk = 0; blk < kBlocks; blk += 2) {
+        if (blk + 1 < kBlocks) fetch(blk + 1, a[1], b[1]);
 #pragma unroll
-        for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][u], b[0][u], acc, 0, 0, 0);
+        if (blk + 1 < kBlocks) {
+            if (blk + 2 < kBlocks) fetch(blk + 2, a[0], b[0]);
+#pragma unroll
+            for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][u], b[1][u], acc, 0, 0, 0);
+        }
     }
     const int col = col0 + fr;
     const float bias = c1[col];

@@ -9,6 +9,7 @@ R=$PWD
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 P="--output-format csv"
+rm -rf $R/gpurun_out/pmc_${TAG}_dep_A $R/gpurun_out/pmc_${TAG}_dep_B $R/gpurun_out/pmc_${TAG}_depmfma_A $R/gpurun_out/pmc_${TAG}_depmfma_B $R/gpurun_out/prof_${TAG}_depmfma
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
 B="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES"
 D="python3 $R/tools/prof_deployed.py"
@@ -17,10 +18,10 @@ for pass in A B; do
   rocprofv3 --pmc $C $P -d $R/gpurun_out/pmc_${TAG}_dep_$pass -- $D f32 bf16 f16 u8 > $R/gpurun_out/pmc_${TAG}_dep_$pass.log 2>&1
   export MDC_DEP_F32_MFMA=1
   rocprofv3 --pmc $C $P -d $R/gpurun_out/pmc_${TAG}_depmfma_$pass -- $D f32 u8 > $R/gpurun_out/pmc_${TAG}_depmfma_$pass.log 2>&1
-  unset MDC_DEP_F32_VALU
+  unset MDC_DEP_F32_MFMA
   echo "pass $pass done"
 done
-rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_dep -- $D f32 bf16 f16 u8 > $R/gpurun_out/prof_${TAG}_dep.log 2>&1
+# (kernel stats of the default kernels: tools/collect_profiles.sh, prof_${TAG}_dep)
 export MDC_DEP_F32_MFMA=1
 rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_depmfma -- $D f32 u8 > $R/gpurun_out/prof_${TAG}_depmfma.log 2>&1
 echo "kernel stats done"
