@@ -10,9 +10,12 @@ R=$PWD
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 P="--output-format csv"
-rm -rf $R/gpurun_out/prof_${TAG}_bench $R/gpurun_out/pmc_*_vt $R/gpurun_out/pmc_*_dep $R/gpurun_out/prof_${TAG}_dep
+rm -rf $R/gpurun_out/prof_${TAG}_bench $R/gpurun_out/prof_${TAG}_bench_extras $R/gpurun_out/pmc_*_vt $R/gpurun_out/pmc_*_dep $R/gpurun_out/prof_${TAG}_dep
 if [ "$2" != "dep" ]; then
-rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench -- python3 $R/bench.py --steps 10 --warmup 3 > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
+# the headline kernels at the headline launch size only (the extra legs launch the same kernels at other sizes -- one
+# window, 65,536 f32 frames -- which would mix into the per-kernel averages): --no-extras; the extras get their own file
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench_extras -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_bench_extras.log 2>&1
 echo "kernel stats done"
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt -- $B > $R/gpurun_out/pmc_fetch_vt.log 2>&1
