@@ -36,6 +36,46 @@ def test_binding_loads_and_reports_errors_without_gpu():
     assert L.mdc_workspace_bytes(None, 10) == 0
 
 
+def test_new_entry_points_validate_their_arguments_without_gpu():
+    """ABI v2 additions reject bad arguments before any device call (so this runs on a GPU-less host)."""
+    L = _cabi.lib()
+    L.mdc_last_error.restype = ctypes.c_char_p
+    assert L.mdc_forward_iq_u8(None, None, 1, 128, 1.0, None, None, None, 0, None) == -22 and b"null model" in L.mdc_last_error()
+    assert L.mdc_confusion_binned(None, None, None, -1, 3, 2, None, None, None) == -22
+    assert L.mdc_confusion_binned(None, None, None, 5, 3, 2, None, None, None) == -22 and b"null labels" in L.mdc_last_error()
+    one = (ctypes.c_int64 * 1)()
+    assert L.mdc_confusion_binned(None, None, None, 0, 3, 0, ctypes.addressof(one), None, None) == -22 and b"bins" in L.mdc_last_error()
+    assert L.mdc_confusion_binned(None, None, None, 0, 3, 4, ctypes.addressof(one), None, None) == 0       # n = 0: nothing to launch
+    assert L.mdc_confusion(None, None, 0, 99, ctypes.addressof(one), None, None) == -22 and b"classes" in L.mdc_last_error()
+    assert L.mdc_iq_u8_windows(None, 4, 0, 1.0, None, None) == -22 and b"hop" in L.mdc_last_error()
+    assert L.mdc_iq_u8_windows(None, 4, 16, 1.0, None, None) == -22 and b"null buffer" in L.mdc_last_error()
+    assert L.mdc_iq_u8_windows(None, 0, 16, 1.0, None, None) == 0
+    assert L.mdc_iq_u8_to_frames(None, -1, 1.0, None, None) == -22
+    assert L.mdc_forward_q612(None, None, 0, 1, None, None, None) == -22
+    assert L.mdc_set_fp8_input_absmax(None, 1.0) == -22
+    assert L.mdc_profile_read(None, 0, None, None) == -22 and L.mdc_profile_reset(None) == -22 and L.mdc_set_profiling(None, 1) == -22
+    L.mdc_destroy(None)                                                                                   # a no-op, not a crash
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/mdc.h compiles as C99 with -Wall -Werror -pedantic and nothing but the standard headers."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 2 && MDC_HOP_FRAME == 128 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "hdr")], check=True)
+    assert subprocess.run([str(tmp_path / "hdr")]).returncode == 0
+
+
+def test_build_cache_is_keyed_on_flags(tmp_path, monkeypatch):
+    """a build with other flags (a -DMDC_ABLATIONS probe build) must not leave objects for a plain build."""
+    import hashlib
+    import modulationdetectioncnn_amd.build as b
+    key = hashlib.sha256(" ".join(b.CXXFLAGS).encode()).hexdigest()
+    b.build()
+    assert open(b.STAMP).read().strip() == key
+    assert hashlib.sha256(" ".join([*b.CXXFLAGS, "-DMDC_ABLATIONS"]).encode()).hexdigest() != key
+
+
 def test_no_oracle_import_in_product():
     pkg = os.path.join(ROOT, "modulationdetectioncnn_amd")
     for dirpath, _, files in os.walk(pkg):
