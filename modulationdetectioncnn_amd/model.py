@@ -132,7 +132,12 @@ class VTCNN2:
         else:
             raise ValueError(f"unknown weight file type: {filepath}")
 
-    def set_weights(self, weights: Sequence[Tuple[np.ndarray, np.ndarray]]) -> None:
+    def set_weights(self, weights: Sequence[Tuple[np.ndarray, np.ndarray]], theano_kernels: bool = False) -> None:
+        """[(kernel, bias)] per weighted layer in the layouts of `Topology.layer_shapes`.  The kernels are applied as
+        Keras-2/TensorFlow applies them: cross-correlation.  `theano_kernels=True` is for a checkpoint trained with
+        Keras 1 on the Theano backend, as the vendored DeepSig notebook was (RML2016.10a_VTCNN2_example.ipynb:229-243
+        under `K.set_image_dim_ordering('th')`): Theano's conv2d CONVOLVES, i.e. applies each filter flipped along both
+        spatial axes, so the 4-D kernels are flipped once here and everything below stays a correlation."""
         shapes = self.topology.layer_shapes
         if len(weights) != len(shapes):
             raise ValueError(f"expected {len(shapes)} (kernel, bias) pairs, got {len(weights)}")
@@ -140,6 +145,9 @@ class VTCNN2:
         for i, ((k, b), (ks, bs)) in enumerate(zip(weights, shapes)):
             k = np.ascontiguousarray(k, dtype=np.float32)
             b = np.ascontiguousarray(b, dtype=np.float32)
+            if theano_kernels and k.ndim == 4:
+                sp = (2, 3) if self.topology.kind == "vtcnn2" else (0, 1)      # OIHW / HWIO: the two spatial axes
+                k = np.ascontiguousarray(np.flip(k, axis=sp))
             if tuple(k.shape) != ks or tuple(b.shape) != bs:
                 raise ValueError(f"layer {i} ({self.topology.layer_names[i]}): expected kernel {ks} bias {bs}, got {k.shape} {b.shape}")
             out.append((k, b))

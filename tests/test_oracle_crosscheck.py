@@ -96,3 +96,30 @@ def test_torch_port_matches_numpy_oracle(kind):
     decided = (srt[:, -1] - srt[:, -2]) > 1e-5
     assert (a["labels"][decided] == b["labels"][decided]).all()
     assert OT.forward(kind, x[:0], w)["probs"].shape[0] == 0
+
+
+def test_theano_kernel_flip_is_a_true_convolution():
+    """`set_weights(..., theano_kernels=True)` (a Keras-1/Theano checkpoint of the canonical VT-CNN2): flipping the 4-D
+    kernels once turns the correlation every path computes into Theano's convolution.  Checked on the host against
+    scipy.signal.convolve2d for conv1 of the canonical net (no GPU needed: only the weight handling is under test)."""
+    from scipy.signal import convolve2d, correlate2d
+    from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_weights
+    topo = Topology.vtcnn2(3)
+    w = synthetic_weights(topo, seed=4)
+    m = VTCNN2(topo, device=0)
+    m.set_weights(w, theano_kernels=True)
+    k_th = w[0][0]                                   # (256,1,1,3) as a Theano checkpoint stores it
+    k_used = m.get_weights()[0][0]                   # what the correlation kernels will see
+    np.testing.assert_array_equal(k_used, k_th[:, :, ::-1, ::-1])
+    x = np.random.default_rng(0).standard_normal((2, 132)).astype(np.float64)
+    for c in (0, 17, 255):
+        np.testing.assert_allclose(correlate2d(x, k_used[c, 0].astype(np.float64), mode="valid"),
+                                   convolve2d(x, k_th[c, 0].astype(np.float64), mode="valid"), atol=1e-12)
+    m2 = VTCNN2(topo, device=0)
+    m2.set_weights(w)                                # default: Keras-2 semantics, kernels untouched
+    np.testing.assert_array_equal(m2.get_weights()[1][0], w[1][0])
+    # deployed nets (HWIO): the flip is over axes (0, 1)
+    d = VTCNN2(Topology.deployed(3, 3), device=0)
+    wd = synthetic_weights(Topology.deployed(3, 3), seed=1)
+    d.set_weights(wd, theano_kernels=True)
+    np.testing.assert_array_equal(d.get_weights()[0][0], wd[0][0][::-1, ::-1])
