@@ -52,11 +52,12 @@ WORKLOADS = {
     "deployed3-f16-n2^20": ("deployed", 3, 3, "f16", 1 << 20, "3convmodrecnets_CNN2_0.5 (bundled)"),         # conv in packed f16, dense on f16 MFMA
     "deployed10-f16-n2^20": ("deployed", 10, 3, "f16", 1 << 20, "convmodrecnets_CNN2_0.5 (bundled)"),
     "deployed3-f32-n2^21": ("deployed", 3, 3, "f32", 1 << 21, "3convmodrecnets_CNN2_0.5 (bundled)"),        # configs[3], T1 reading
+    "deployed3-fp8-n2^20": ("deployed", 3, 3, "fp8", 1 << 20, "5convmodrecnets_CNN2_0.5 (bundled)"),         # configs[4] read literally: that file, fp8 MFMA
     "cnnpy-f32-n2^20": ("cnnpy", 10, 5, "f32", 1 << 20, "synthetic seed 2016"),                           # cnn.py literal model
 }
 DEFAULT = "vtcnn2-c11-bf16-n2^20"
 EXTRAS = ["vtcnn2-c3-f32-n65536", "vtcnn2-c11-fp8-n2^20", "deployed3-f32-n2^20", "deployed10-f32-n2^20",
-          "deployed3-bf16-n2^20", "deployed10-bf16-n2^20", "deployed3-f16-n2^20", "deployed10-f16-n2^20"]
+          "deployed3-bf16-n2^20", "deployed10-bf16-n2^20", "deployed3-f16-n2^20", "deployed10-f16-n2^20", "deployed3-fp8-n2^20"]
 
 
 def make_model(name, device):
@@ -69,6 +70,8 @@ def make_model(name, device):
     else:
         g = os.path.join(ROOT, "tests", "golden", "weights")
         f = "3convmodrecnets_CNN2_0.5.npz" if filters == 3 else "convmodrecnets_CNN2_0.5.npz"
+        if name == "deployed3-fp8-n2^20":
+            f = "5convmodrecnets_CNN2_0.5.npz"
         m = VTCNN2.from_npz(os.path.join(g, f), device=device, dtype=dtype)
     return m, n, dtype
 

@@ -60,8 +60,9 @@ enum {
  * and dense1's operands) and MDC_KIND_DEPLOYED (the dense layer's operands; the conv stays f32; no layer taps).
  * MDC_F16: MDC_KIND_DEPLOYED only -- as MDC_BF16 there, with IEEE f16 operands and the conv itself in packed f16
  * (11 significant bits instead of 8, but conv outputs must stay below 65,504).
- * MDC_FP8: MDC_KIND_VTCNN2 only -- conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16); the
- * activations are scaled for the largest |sample| given with mdc_set_fp8_input_absmax -- beyond it they saturate. */
+ * MDC_FP8: MDC_KIND_VTCNN2 -- conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16) -- and
+ * MDC_KIND_DEPLOYED -- as MDC_BF16 there with e4m3 operands (BASELINE configs[4] read literally); the activations are
+ * scaled for the largest |sample| given with mdc_set_fp8_input_absmax -- beyond it they saturate. */
 enum { MDC_F32 = 0, MDC_BF16 = 1, MDC_FP8 = 2, MDC_F16 = 3 };
 
 /* Layer taps of CNN.ipynb cell 17.  tap_dev receives, per frame:

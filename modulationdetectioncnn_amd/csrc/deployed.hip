@@ -439,7 +439,7 @@ int deployed_pack(mdc_model* m) {
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
                      float* tap, int tap_kind, hipStream_t s) {
     if (tap_kind == MDC_TAP_HIDDEN) { set_error("deployed nets have no hidden dense layer to tap"); return MDC_EINVAL; }
-    if (m->dtype == MDC_BF16 || m->dtype == MDC_F16) {
+    if (m->dtype != MDC_F32) {      // bf16 / f16 / fp8: the dense layer on the matrix cores (deployed_bf16.hip)
         if (tap_kind != MDC_TAP_NONE) { set_error("layer taps of the deployed nets are served by the f32 kernels (finalize with MDC_F32)"); return MDC_ENOTSUP; }
         return deployed_bf16_forward(m, x, n, probs, labels, s);
     }

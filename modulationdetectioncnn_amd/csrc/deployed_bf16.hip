@@ -23,7 +23,13 @@
 // registers: two filters per instruction at the plain VALU rate, ReLU = one v_pk_max_f16, no conversion before the
 // MFMA), which is what lifts the F = 10 net off the v_pk_fma_f32 bound.  f16 keeps 11 significant bits (bf16: 8) but
 // only ~5 decades of range: conv outputs must stay below 65,504.
-// Both: products accumulated in f32 by the MFMA; bias, ReLU, softmax, first-max argmax in f32 as in deployed.hip.
+// FP8 (MDC_FP8, round 2: BASELINE configs[4] read literally -- "5convmodrecnets_CNN2_0.5.wts.h5, fp8 MFMA path"): the
+// bf16 mode's f32 conv, its outputs and the dense weights as OCP e4m3 on v_mfma_f32_16x16x32_fp8_fp8 (8 one-byte k values
+// per lane).  e4m3 spans 2^-9 .. 448, so the conv's taps and bias are multiplied by 2^sa (sa from the largest |sample| the
+// caller states, mdc_set_fp8_input_absmax, default 0.02) and the dense weights by 2^sw on the host -- powers of two,
+// exact -- and the class sums are multiplied by 2^-(sa+sw) before the dense bias; ReLU is v_med3_f32(y, 0, 448), which also
+// saturates an input beyond the stated range instead of letting it become NaN.
+// All: products accumulated in f32 by the MFMA; bias, ReLU, softmax, first-max argmax in f32 as in deployed.hip.
 #include "vtcnn2_bf16_common.h"
 
 #include <algorithm>
@@ -70,16 +76,24 @@ struct Bf16Geom {
 using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
+// four f32 -> four e4m3 in one dword (byte i = value i), ReLU and saturation at the e4m3 maximum by one v_med3_f32 each
+__device__ __forceinline__ unsigned pack4relu_fp8(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, 0.f, 448.f), __builtin_amdgcn_fmed3f(b, 0.f, 448.f), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, 0.f, 448.f), __builtin_amdgcn_fmed3f(d, 0.f, 448.f), w, true);
+    return (unsigned)w;
+}
+
 // U8 = true (mdc_forward_iq_u8): x points at raw interleaved unsigned 8-bit (I,Q) samples, 256 B per frame.  A whole
 // group is then 4 KiB (one DMA instruction = four frames), the wave's staging area holds a ring of FOUR groups
 // (three in flight while one is computed), and a lane reads the 8 bytes that hold its four samples of both rows and
 // converts the row at hand with the arithmetic of mdc_iq_u8_to_frames -- the f32 samples, and so every result, are
 // bit-identical to convert-then-forward.
-template <int F, bool HALF, bool U8>
+template <int F, int MODE, bool U8>      // MODE: 0 bf16, 1 f16, 2 fp8 (e4m3)
 __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __restrict__ x, long n,
                                                                 const float* __restrict__ wp, const uint4* __restrict__ atab,
                                                                 float* __restrict__ probs, int* __restrict__ labels, float scale, long hop2) {
     using G = Bf16Geom<F>;
+    constexpr bool HALF = MODE == 1, FP8 = MODE == 2;
     constexpr int kPhaseUnits = G::kUnits / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* a_lds = reinterpret_cast<uint4*>(smem);
@@ -101,6 +115,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
     for (int i = 0; i < F; ++i) { k0[i] = wp[3 * i + 0]; k1[i] = wp[3 * i + 1]; cb[i] = wp[3 * i + 2]; }
 #pragma unroll
     for (int c = 0; c < kC; ++c) bd[c] = wp[3 * F + c];
+    const float unscale = FP8 ? wp[3 * F + kC] : 1.f;      // fp8: 2^-(sa+sw), exact
     // f16 mode: taps and bias as f16 pairs (filters f, f+1); an odd F gets a zero partner
     h16x2 k0h[(F + 1) / 2], k1h[(F + 1) / 2], cbh[(F + 1) / 2];
 #pragma unroll
@@ -237,8 +252,13 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                             }
                         }
                     }
+                    if constexpr (FP8) {
 #pragma unroll
-                    for (int i = 0; i < G::kUnitVals / 2; ++i) pk[i] = pack2relu(vals[2 * i], vals[2 * i + 1]);
+                        for (int i = 0; i < G::kUnitVals / 4; ++i) pk[i] = pack4relu_fp8(vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < G::kUnitVals / 2; ++i) pk[i] = pack2relu(vals[2 * i], vals[2 * i + 1]);
+                    }
                 } else {
                     _Float16 hv[G::kUnitVals];
 #pragma unroll
@@ -264,9 +284,15 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
 #pragma unroll
                 for (int mm = 0; mm < G::kUnitMfma; ++mm) {
                     const int m = u * G::kUnitMfma + mm;
-                    const u32x4 b = u32x4{pk[4 * mm + 0], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]};
-                    if constexpr (HALF) acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a[mm]), __builtin_bit_cast(h16x8, b), acc[m & 1], 0, 0, 0);
-                    else acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mm]), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+                    if constexpr (FP8) {
+                        const long b8 = (long)(((unsigned long)pk[2 * mm + 1] << 32) | pk[2 * mm]);
+                        const long a8 = (long)(((unsigned long)a[mm].y << 32) | a[mm].x);
+                        acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, b8, acc[m & 1], 0, 0, 0);
+                    } else {
+                        const u32x4 b = u32x4{pk[4 * mm + 0], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]};
+                        if constexpr (HALF) acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a[mm]), __builtin_bit_cast(h16x8, b), acc[m & 1], 0, 0, 0);
+                        else acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mm]), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep each unit's values inside the unit (register budget)
             }
@@ -307,6 +333,10 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                         w[i] = __builtin_bit_cast(unsigned, h16x2{e[0], e[1]});
                     }
                     acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, u32x4{w[0], w[1], w[2], w[3]}), acc[m & 1], 0, 0, 0);
+                } else if constexpr (FP8) {
+                    const unsigned lo = pack4relu_fp8(ev[8 * mm + 0], ev[8 * mm + 1], ev[8 * mm + 2], ev[8 * mm + 3]);
+                    const unsigned hi = pack4relu_fp8(ev[8 * mm + 4], ev[8 * mm + 5], ev[8 * mm + 6], ev[8 * mm + 7]);
+                    acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(((unsigned long)a.y << 32) | a.x), (long)(((unsigned long)hi << 32) | lo), acc[m & 1], 0, 0, 0);
                 } else {
                     const u32x4 b = u32x4{pack2relu(ev[8 * mm + 0], ev[8 * mm + 1]), pack2relu(ev[8 * mm + 2], ev[8 * mm + 3]),
                                           pack2relu(ev[8 * mm + 4], ev[8 * mm + 5]), pack2relu(ev[8 * mm + 6], ev[8 * mm + 7])};
@@ -316,9 +346,10 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
         }
         // D rows 0..2 (the classes) of column f live in lanes 0..15 (kg = 0), registers 0..2
         if (g == 0 && frame < n) {
-            const float z0 = fmaxf(acc[0][0] + acc[1][0] + bd[0], 0.f);      // Dense(3, activation='relu')
-            const float z1 = fmaxf(acc[0][1] + acc[1][1] + bd[1], 0.f);
-            const float z2 = fmaxf(acc[0][2] + acc[1][2] + bd[2], 0.f);
+            // Dense(3, activation='relu'); fp8: the sums carry 2^(sa+sw), removed exactly before the bias
+            const float z0 = fmaxf(FP8 ? fmaf(acc[0][0] + acc[1][0], unscale, bd[0]) : acc[0][0] + acc[1][0] + bd[0], 0.f);
+            const float z1 = fmaxf(FP8 ? fmaf(acc[0][1] + acc[1][1], unscale, bd[1]) : acc[0][1] + acc[1][1] + bd[1], 0.f);
+            const float z2 = fmaxf(FP8 ? fmaf(acc[0][2] + acc[1][2], unscale, bd[2]) : acc[0][2] + acc[1][2] + bd[2], 0.f);
             const float mx = fmaxf(z0, fmaxf(z1, z2));
             const float e0 = expf(z0 - mx), e1 = expf(z1 - mx), e2 = expf(z2 - mx);
             const float inv = 1.0f / (e0 + e1 + e2);
@@ -358,8 +389,28 @@ inline unsigned short f2h(float f) {
     return (unsigned short)(sign | h);
 }
 
+// e4m3 (OCP "fn": no infinities, max 448, NaN = 0x7F), round-to-nearest-even, saturating
+inline unsigned char f2e4m3_sat(float f) {
+    if (std::isnan(f)) return 0x7F;
+    const unsigned char sign = std::signbit(f) ? 0x80 : 0x00;
+    const float a = std::fabs(f);
+    if (a >= 448.f) return sign | 0x7E;
+    if (a < std::ldexp(1.f, -10)) return sign;                       // below half the smallest subnormal (2^-9)
+    int e;
+    (void)std::frexp(a, &e);                                         // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;
+    if (E < -6) E = -6;                                              // subnormal: fixed exponent
+    int mnt = (int)std::nearbyint(std::ldexp(a, 3 - E));             // 3 fractional bits (RNE by default)
+    if (mnt == 16) { mnt = 8; ++E; }
+    if (E > 8 || (E == 8 && mnt > 14)) return sign | 0x7E;
+    if (mnt < 8) return sign | (unsigned char)mnt;                   // subnormal: exponent field 0
+    return sign | (unsigned char)(((E + 7) << 3) | (mnt - 8));
+}
+
+// The dense layer as MFMA A operands, [mfma][k-group][class][16 bytes]: 8 bf16 / f16, or 8 e4m3 (x wscale) in the
+// first 8 bytes of the entry
 template <int F>
-void pack_atab(const mdc_model* m, std::vector<unsigned short>& tab) {
+void pack_atab(const mdc_model* m, std::vector<unsigned short>& tab, float wscale) {
     using G = Bf16Geom<F>;
     tab.assign((size_t)G::kATabBytes / 2, 0);
     const float* dk = m->hk[1].data();      // (258F, 3), rows h*129F + w*F + f
@@ -380,36 +431,61 @@ void pack_atab(const mdc_model* m, std::vector<unsigned short>& tab) {
                             w = dk[((size_t)h * 129 * F + ff) * kC + c];      // position 0
                         }
                     }
-                    tab[(((size_t)mi * 4 + kg) * kC + c) * 8 + i] = m->dtype == MDC_F16 ? f2h(w) : f2bf(w);
+                    const size_t entry = (((size_t)mi * 4 + kg) * kC + c) * 8;      // in 16-bit units
+                    if (m->dtype == MDC_FP8) reinterpret_cast<unsigned char*>(&tab[entry])[i] = f2e4m3_sat(w * wscale);
+                    else tab[entry + i] = m->dtype == MDC_F16 ? f2h(w) : f2bf(w);
                 }
 }
 
 }  // namespace
 
-// d_pack slot 2: the dense layer as MFMA A operands (bf16)
+// d_pack slot 2: the dense layer as MFMA A operands (bf16 / f16 / e4m3).  fp8 mode also builds its own head (slot 4):
+// conv taps and bias x 2^sa, dense bias, 2^-(sa+sw) -- the f32 head of slot 0 stays as it is for the Q6.12 tables' sake.
 int deployed_bf16_pack(mdc_model* m) {
+    const int F = m->topo.filters;
+    float wscale = 1.f;
+    if (m->dtype == MDC_FP8) {
+        const float* ck = m->hk[0].data();   // HWIO (1,2,1,F): [kw][f]
+        float cbound = 0.f, wmax = 0.f;
+        for (int f = 0; f < F; ++f) cbound = std::fmax(cbound, m->fp8_input_absmax * (std::fabs(ck[f]) + std::fabs(ck[F + f])) + std::fabs(m->hb[0][f]));
+        for (float w : m->hk[1]) wmax = std::fmax(wmax, std::fabs(w));
+        if (!(cbound > 0.f) || !(wmax > 0.f)) { set_error("fp8: degenerate weights (all zero)"); return MDC_EINVAL; }
+        const int sa = (int)std::floor(std::log2(224.f / cbound)), sw = (int)std::floor(std::log2(224.f / wmax));      // a factor 2 of head-room
+        const float fsa = std::ldexp(1.f, sa);
+        wscale = std::ldexp(1.f, sw);
+        std::vector<float> head(64, 0.f);
+        for (int f = 0; f < F; ++f) {
+            head[3 * f + 0] = ck[f] * fsa;
+            head[3 * f + 1] = ck[F + f] * fsa;
+            head[3 * f + 2] = m->hb[0][f] * fsa;
+        }
+        for (int c = 0; c < kC; ++c) head[3 * F + c] = m->hb[1][c];
+        head[3 * F + kC] = std::ldexp(1.f, -(sa + sw));
+        const int rc = upload(m, 4, head.data(), head.size() * sizeof(float));
+        if (rc != MDC_OK) return rc;
+    }
     std::vector<unsigned short> tab;
-    if (m->topo.filters == 3) pack_atab<3>(m, tab);
-    else pack_atab<10>(m, tab);
+    if (F == 3) pack_atab<3>(m, tab, wscale);
+    else pack_atab<10>(m, tab, wscale);
     return upload(m, 2, tab.data(), tab.size() * sizeof(unsigned short));
 }
 
 template <int F, bool U8>
 static int launch_bf16(const mdc_model* m, const void* x, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s, long hop2 = 256) {
     using G = Bf16Geom<F>;
-    const float* wp = static_cast<const float*>(m->d_pack[0]);
+    const float* wp = static_cast<const float*>(m->d_pack[m->dtype == MDC_FP8 ? 4 : 0]);
     const uint4* atab = static_cast<const uint4*>(m->d_pack[2]);
     const float* xf = static_cast<const float*>(x);
     const long ngroups = (n + 15) / 16;
     long grid = (ngroups + G::kWaves - 1) / G::kWaves;
     if (grid > 256) grid = 256;      // one work-group per CU (LDS: A table + 8 x 2 row buffers)
-    if (m->dtype == MDC_F16) {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, true, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
-        hipLaunchKernelGGL((deployed_bf16_kernel<F, true, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale, hop2);
-    } else {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, false, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
-        hipLaunchKernelGGL((deployed_bf16_kernel<F, false, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale, hop2);
-    }
+#define MDC_LAUNCH_DEP16(MODE) do { \
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_bf16_kernel<F, MODE, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds)); \
+        hipLaunchKernelGGL((deployed_bf16_kernel<F, MODE, U8>), dim3((unsigned)grid), dim3(64 * G::kWaves), G::kLds, s, xf, (long)n, wp, atab, probs, labels, scale, hop2); } while (0)
+    if (m->dtype == MDC_F16) MDC_LAUNCH_DEP16(1);
+    else if (m->dtype == MDC_FP8) MDC_LAUNCH_DEP16(2);
+    else MDC_LAUNCH_DEP16(0);
+#undef MDC_LAUNCH_DEP16
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

@@ -192,7 +192,7 @@ int mdc_finalize(mdc_model* m, int dtype) {
             if (!m->have[l]) { set_error("mdc_finalize: layer %d has no weights", l); return MDC_ESTATE; }
         if (dtype != MDC_F32 && dtype != MDC_BF16 && dtype != MDC_FP8 && dtype != MDC_F16) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
         if (dtype == MDC_F16 && m->topo.kind != MDC_KIND_DEPLOYED) { set_error("f16 is implemented for the deployed nets only"); return MDC_ENOTSUP; }
-        if (dtype == MDC_FP8 && m->topo.kind != MDC_KIND_VTCNN2) { set_error("fp8 is implemented for the vtcnn2 family only"); return MDC_ENOTSUP; }
+        if (dtype == MDC_FP8 && m->topo.kind == MDC_KIND_CNNPY) { set_error("fp8 is implemented for the vtcnn2 and deployed families only"); return MDC_ENOTSUP; }
         if (dtype == MDC_BF16 && m->topo.kind == MDC_KIND_CNNPY) { set_error("bf16 is implemented for the vtcnn2 and deployed families only"); return MDC_ENOTSUP; }
         m->dtype = dtype;
         DeviceScope dev(m->device);      // uploads go to the model's device; the caller's current device is restored
@@ -202,7 +202,7 @@ int mdc_finalize(mdc_model* m, int dtype) {
             case MDC_KIND_DEPLOYED:
                 rc = deployed_pack(m);
                 if (rc == MDC_OK) rc = deployed_q612_pack(m);
-                if (rc == MDC_OK && (dtype == MDC_BF16 || dtype == MDC_F16)) rc = deployed_bf16_pack(m);
+                if (rc == MDC_OK && dtype != MDC_F32) rc = deployed_bf16_pack(m);
                 break;
             case MDC_KIND_VTCNN2:   rc = vtcnn2_pack(m); break;
             case MDC_KIND_CNNPY:    rc = cnnpy_pack(m); break;

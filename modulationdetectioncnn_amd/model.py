@@ -45,8 +45,8 @@ class VTCNN2:
 
     def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
                  fp8_input_absmax: Optional[float] = None):
-        """dtype "f32" | "bf16" (vtcnn2, deployed) | "f16" (deployed) | "fp8" (vtcnn2).  fp8_input_absmax: the largest |I/Q sample| the
-        fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs overflow e4m3."""
+        """dtype "f32" | "bf16" (vtcnn2, deployed) | "f16" (deployed) | "fp8" (vtcnn2, deployed).  fp8_input_absmax: the largest
+        |I/Q sample| the fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs saturate."""
         self.topology = topology
         self.dtype = dtype
         self.fp8_input_absmax = fp8_input_absmax

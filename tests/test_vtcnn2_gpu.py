@@ -116,10 +116,7 @@ def test_f32_larger_batch_statistics():
 
 
 def test_fp8_rejects_other_topologies_and_bad_scale():
-    from conftest import load_deployed_npz
-    w = load_deployed_npz("3convmodrecnets_CNN2_0.5")
-    m = VTCNN2(Topology.deployed(3, 3), dtype="fp8")
-    m.set_weights(w)
+    m = VTCNN2.synthetic("cnnpy", classes=5, dtype="fp8")          # fp8: vtcnn2 and deployed, not the cnn.py literal model
     with pytest.raises(Exception):
         m.predict(np.zeros((1, 2, 128), np.float32))
     topo, wv = _setup(3)

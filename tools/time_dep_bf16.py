@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Deployed nets: frames/s of the f32 kernels and of the bf16 mode (dense layer on the matrix cores) on 2^21 frames."""
+"""Deployed nets: frames/s of the f32 kernels and of the bf16 / f16 / fp8 modes (dense layer on the matrix cores) on 2^21 frames."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from modulationdetectioncnn_amd import VTCNN2, synthetic_frames
@@ -8,7 +8,7 @@ n = 1 << 21
 x = synthetic_frames(n, seed=2016, device="cuda:0")
 probs = torch.empty((n, 3), dtype=torch.float32, device="cuda"); labels = torch.empty((n,), dtype=torch.int32, device="cuda")
 for topo in ("deployed3", "deployed10"):
-    for dt in ("f32", "bf16", "f16"):
+    for dt in ("f32", "bf16", "f16", "fp8"):
         m = VTCNN2.synthetic(topo, seed=2016, device=0, dtype=dt)
         for _ in range(3): m.forward_device(x, probs, labels)
         torch.cuda.synchronize(); t = time.perf_counter()
