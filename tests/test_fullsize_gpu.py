@@ -27,7 +27,9 @@ CASES = [("vtcnn2", "bf16", 1 << 20, 11), ("vtcnn2", "fp8", 1 << 18, 11), ("vtcn
          ("vtcnn2", "bf16", 1 << 21, 11), ("deployed3", "f32", 1 << 21, 3),
          # configs[2] read literally (convmodrecnets_CNN2_0.5.wts.h5 = the 10-filter deployed net, bf16) and configs[4]'s
          # per-GPU shard in fp8 (2^20 / 8 = 2^17 frames) is covered by the 2^18 fp8 case above
-         ("deployed10", "bf16", 1 << 20, 3), ("deployed3", "bf16", 1 << 20, 3), ("deployed10", "f16", 1 << 20, 3)]
+         ("deployed10", "bf16", 1 << 20, 3), ("deployed3", "bf16", 1 << 20, 3), ("deployed10", "f16", 1 << 20, 3),
+         # configs[4] read literally: a T1 checkpoint on the fp8 MFMA path, its per-GPU shard 2^20 / 8 = 2^17 frames
+         ("deployed3", "fp8", 1 << 17, 3)]
 
 
 def _model(kind, dtype, classes):
@@ -79,7 +81,9 @@ def test_fullsize_properties(kind, dtype, n, classes):
     ref = O.forward(okind, xs, w, dtype=np.float64)
     tol = {"f32": 2e-5, "bf16": 2e-2, "f16": 2e-2, "fp8": 8e-2}[dtype]
     got = p[sub].cpu().numpy()
-    if kind.startswith("deployed") and dtype != "f32":
+    if kind.startswith("deployed") and dtype == "fp8":
+        bound = 6e-2        # e4m3 operands (tests/test_deployed_gpu.py::test_fp8_mode_of_the_deployed_nets)
+    elif kind.startswith("deployed") and dtype != "f32":
         bound = 1e-2        # the 16-bit deployed modes' bar (tests/test_deployed_gpu.py): probabilities within 1e-2
     else:
         bound = max(2e-6, 2 * tol * np.abs(ref.get("logits", ref.get("dense"))).max())
