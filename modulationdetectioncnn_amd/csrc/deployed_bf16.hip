@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long fr = grp * 16 + i + 8 * (lane >> 5);
-            glds16(x + (fr < n ? fr : n - 1) * kFrameFloats + r * kSamples + (lane & 31) * 4, stage + r * G::kStageBytes + i * G::kPairStride);
+            glds16_async(x + (fr < n ? fr : n - 1) * kFrameFloats + r * kSamples + (lane & 31) * 4, stage + r * G::kStageBytes + i * G::kPairStride);
         }
     };
     // raw bytes: ring slot of a group = 4 DMA instructions (4 frames x 256 B each) at stage + slot * kRawGroup
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long fr = gc * 16 + 4 * i + (lane >> 4);
-            glds16(xb + (fr < n ? fr : n - 1) * hop2 + (lane & 15) * 16, stage + slot * kRawGroup + i * G::kPairStride);
+            glds16_async(xb + (fr < n ? fr : n - 1) * hop2 + (lane & 15) * 16, stage + slot * kRawGroup + i * G::kPairStride);
         }
     };
     // raw bytes: the 8 bytes of piece 4jj + g (samples of BOTH rows) of frame f at rawmine + slot * kRawGroup + 32 jj

@@ -110,9 +110,9 @@ __global__ __launch_bounds__(512, 2) void deployed_f32m_kernel(const float* __re
             long fr = grp * 4 + i;
             fr = fr < n ? fr : n - 1;      // frames past the end re-read the last one (never stored)
             if constexpr (U8) {
-                if (lane < 16) glds16(reinterpret_cast<const unsigned char*>(x) + fr * hop2 + lane * 16, dst + i * G::kFrameStride);
+                if (lane < 16) glds16_async(reinterpret_cast<const unsigned char*>(x) + fr * hop2 + lane * 16, dst + i * G::kFrameStride);
             } else {
-                glds16(x + fr * kFrameFloats + lane * 4, dst + i * G::kFrameStride);
+                glds16_async(x + fr * kFrameFloats + lane * 4, dst + i * G::kFrameStride);
             }
         }
     };

@@ -100,6 +100,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy issued from inline asm (M0 = the wave's LDS destination through the "{m0}" constraint).  hipcc tracks a
+// builtin LDS-DMA as an asynchronous LDS store and, having no alias scopes to tell ring slots apart, puts an
+// s_waitcnt vmcnt(0) in front of EVERY later LDS read -- so a ring of several groups "in flight" drained completely at
+// each step, counted waits or not (found in round 2 in the ISA of the deployed kernels: `s_waitcnt vmcnt(12)` followed by
+// `s_waitcnt vmcnt(0)`).  With the asm form the kernel's own counted waits are the only ones; the kernel is then
+// responsible for both orderings: DMA landed before its slot is read (counted vmcnt), slot read out before it is
+// refilled (lgkmcnt(0) before the refill is issued).
+__device__ __forceinline__ void glds16_async(const void* gsrc, void* lds_wave_base) {
+    const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+    asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(gsrc), "{m0}"(l) : "memory");
+}
+
 // host-side bf16 conversion for the operand packing
 inline unsigned short f2bf(float f) {          // host RNE f32 -> bf16
     unsigned u;

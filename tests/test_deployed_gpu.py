@@ -143,8 +143,8 @@ def test_empty_and_errors():
     with pytest.raises(ValueError):
         VTCNN2(Topology.deployed(3)).set_weights(load_deployed_npz("convmodrecnets_CNN2_0.5"))
     from modulationdetectioncnn_amd._cabi import MdcError
-    with pytest.raises(MdcError):       # fp8 exists for the vtcnn2 family only
-        VTCNN2.from_npz(os.path.join(GOLDEN, "weights", "3convmodrecnets_CNN2_0.5.npz"), dtype="fp8").predict(np.zeros((1, 2, 128), np.float32))
+    with pytest.raises(MdcError):       # fp8: vtcnn2 and deployed, not the cnn.py literal model
+        VTCNN2.synthetic("cnnpy", classes=5, dtype="fp8").predict(np.zeros((1, 2, 128), np.float32))
     with pytest.raises(MdcError):       # bf16: vtcnn2 and deployed, not the cnn.py literal model
         VTCNN2.synthetic("cnnpy", classes=5, dtype="bf16").predict(np.zeros((1, 2, 128), np.float32))
     with pytest.raises(MdcError):       # f16: the deployed nets only
