@@ -2,7 +2,11 @@
  * runtime's C API for the device buffers the caller owns.  It does for a deployed net (CNN.ipynb cell 6) what the
  * reference does with Keras (cnn.py:147 load_weights, cnn.py:198 predict, cnn.py:209 argmax):
  *
- *     c_client <weights.bin> <frames.bin> <n> <out.bin> [F]
+ *     c_client <weights.bin> <frames.bin> <n> <out.bin> [F [lanes]]
+ *
+ * lanes > 1: the one-process multi-GPU form of BASELINE.json configs[3] ("per-GPU HIP streams") -- one model handle per
+ * visible device, lanes streams dealt round-robin over the devices, the batch cut into contiguous shards, EVERY forward
+ * enqueued from this one host thread before the first synchronisation, each stream synchronised once.
  *
  * weights.bin: float32 conv kernel (2F, HWIO), conv bias (F), dense kernel (258F x 3), dense bias (3);
  * frames.bin:  n x 2 x 128 float32;   out.bin: n x 3 float32 probabilities, then n int32 labels.
@@ -31,43 +35,62 @@ static void* read_file(const char* path, size_t bytes) {
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
 
+#define MAX_LANES 16
+#define MAX_DEVS 16
+
 int main(int argc, char** argv) {
-    if (argc < 5) { fprintf(stderr, "usage: %s weights.bin frames.bin n out.bin [F]\n", argv[0]); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: %s weights.bin frames.bin n out.bin [F [lanes]]\n", argv[0]); return 2; }
     const long n = atol(argv[3]);
     const int F = argc > 5 ? atoi(argv[5]) : 3;
+    int lanes = argc > 6 ? atoi(argv[6]) : 1;
+    if (lanes < 1 || lanes > MAX_LANES) { fprintf(stderr, "lanes must be 1..%d\n", MAX_LANES); return 2; }
     const size_t nk0 = 2 * (size_t)F, nb0 = (size_t)F, nk1 = 258 * (size_t)F * 3, nb1 = 3;
     float* w = (float*)read_file(argv[1], (nk0 + nb0 + nk1 + nb1) * sizeof(float));
     float* x = (float*)read_file(argv[2], (size_t)n * 256 * sizeof(float));
 
     if (mdc_abi_version() != MDC_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (ndev > MAX_DEVS) ndev = MAX_DEVS;
+    if (ndev > lanes) ndev = lanes;                 /* one model per device actually used */
     mdc_topology topo = {MDC_KIND_DEPLOYED, 0, 0, 3, {0, 0, 0, 0}};
     topo.filters = F;
-    mdc_model* m = NULL;
-    MDC_CHECK(mdc_create(&topo, 0, &m));
-    size_t ke = 0, be = 0;
-    MDC_CHECK(mdc_layer_sizes(m, 0, &ke, &be));
-    if (mdc_num_layers(m) != 2 || ke != nk0 || be != nb0) { fprintf(stderr, "unexpected layer sizes\n"); return 1; }
-    MDC_CHECK(mdc_set_weights(m, 0, w, nk0, w + nk0, nb0));
-    MDC_CHECK(mdc_set_weights(m, 1, w + nk0 + nb0, nk1, w + nk0 + nb0 + nk1, nb1));
-    /* calling forward before finalize is an ordering error the library reports, it does not crash */
-    if (mdc_forward(m, x, n, NULL, NULL, NULL, MDC_TAP_NONE, NULL, 0, NULL) != MDC_ESTATE) { fprintf(stderr, "expected MDC_ESTATE\n"); return 1; }
-    MDC_CHECK(mdc_finalize(m, MDC_F32));
+    mdc_model* model[MAX_DEVS];
+    for (int d = 0; d < ndev; ++d) {
+        model[d] = NULL;
+        MDC_CHECK(mdc_create(&topo, d, &model[d]));
+        size_t ke = 0, be = 0;
+        MDC_CHECK(mdc_layer_sizes(model[d], 0, &ke, &be));
+        if (mdc_num_layers(model[d]) != 2 || ke != nk0 || be != nb0) { fprintf(stderr, "unexpected layer sizes\n"); return 1; }
+        MDC_CHECK(mdc_set_weights(model[d], 0, w, nk0, w + nk0, nb0));
+        MDC_CHECK(mdc_set_weights(model[d], 1, w + nk0 + nb0, nk1, w + nk0 + nb0 + nk1, nb1));
+        /* calling forward before finalize is an ordering error the library reports, it does not crash */
+        if (mdc_forward(model[d], x, n, NULL, NULL, NULL, MDC_TAP_NONE, NULL, 0, NULL) != MDC_ESTATE) { fprintf(stderr, "expected MDC_ESTATE\n"); return 1; }
+        MDC_CHECK(mdc_finalize(model[d], MDC_F32));
+    }
 
-    float *x_dev = NULL, *p_dev = NULL;
-    int32_t* l_dev = NULL;
-    hipStream_t s;
-    HIP_CHECK(hipSetDevice(0));
-    HIP_CHECK(hipStreamCreate(&s));
-    HIP_CHECK(hipMalloc((void**)&x_dev, (size_t)(n ? n : 1) * 256 * sizeof(float)));
-    HIP_CHECK(hipMalloc((void**)&p_dev, (size_t)(n ? n : 1) * 3 * sizeof(float)));
-    HIP_CHECK(hipMalloc((void**)&l_dev, (size_t)(n ? n : 1) * sizeof(int32_t)));
-    HIP_CHECK(hipMemcpyAsync(x_dev, x, (size_t)n * 256 * sizeof(float), hipMemcpyHostToDevice, s));
-    MDC_CHECK(mdc_forward(m, x_dev, n, p_dev, l_dev, NULL, MDC_TAP_NONE, NULL, mdc_workspace_bytes(m, n), s));
     float* p = (float*)malloc((size_t)(n ? n : 1) * 3 * sizeof(float));
     int32_t* l = (int32_t*)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
-    HIP_CHECK(hipMemcpyAsync(p, p_dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(l, l_dev, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    float *x_dev[MAX_LANES], *p_dev[MAX_LANES];
+    int32_t* l_dev[MAX_LANES];
+    hipStream_t s[MAX_LANES];
+    long lo[MAX_LANES + 1];
+    for (int i = 0; i <= lanes; ++i) lo[i] = (long)(((long long)i * n) / lanes);      /* contiguous, exhaustive shards */
+    /* enqueue everything: uploads, forwards, downloads -- no synchronisation in this loop */
+    for (int i = 0; i < lanes; ++i) {
+        const int d = i % ndev;
+        const long m = lo[i + 1] - lo[i];
+        HIP_CHECK(hipSetDevice(d));
+        HIP_CHECK(hipStreamCreate(&s[i]));
+        HIP_CHECK(hipMalloc((void**)&x_dev[i], (size_t)(m ? m : 1) * 256 * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&p_dev[i], (size_t)(m ? m : 1) * 3 * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&l_dev[i], (size_t)(m ? m : 1) * sizeof(int32_t)));
+        HIP_CHECK(hipMemcpyAsync(x_dev[i], x + lo[i] * 256, (size_t)m * 256 * sizeof(float), hipMemcpyHostToDevice, s[i]));
+        MDC_CHECK(mdc_forward(model[d], x_dev[i], m, p_dev[i], l_dev[i], NULL, MDC_TAP_NONE, NULL, mdc_workspace_bytes(model[d], m), s[i]));
+        HIP_CHECK(hipMemcpyAsync(p + lo[i] * 3, p_dev[i], (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, s[i]));
+        HIP_CHECK(hipMemcpyAsync(l + lo[i], l_dev[i], (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, s[i]));
+    }
+    for (int i = 0; i < lanes; ++i) HIP_CHECK(hipStreamSynchronize(s[i]));              /* ONE sync per lane */
 
     FILE* out = fopen(argv[4], "wb");
     if (!out || fwrite(p, sizeof(float), (size_t)n * 3, out) != (size_t)n * 3 || fwrite(l, sizeof(int32_t), (size_t)n, out) != (size_t)n) {
@@ -75,10 +98,12 @@ int main(int argc, char** argv) {
         return 1;
     }
     fclose(out);
-    mdc_destroy(m);
-    HIP_CHECK(hipFree(x_dev)); HIP_CHECK(hipFree(p_dev)); HIP_CHECK(hipFree(l_dev));
-    HIP_CHECK(hipStreamDestroy(s));
+    for (int d = 0; d < ndev; ++d) mdc_destroy(model[d]);
+    for (int i = 0; i < lanes; ++i) {
+        HIP_CHECK(hipFree(x_dev[i])); HIP_CHECK(hipFree(p_dev[i])); HIP_CHECK(hipFree(l_dev[i]));
+        HIP_CHECK(hipStreamDestroy(s[i]));
+    }
     free(w); free(x); free(p); free(l);
-    printf("c_client: %ld frames classified\n", n);
+    printf("c_client: %ld frames classified on %d device(s), %d stream(s)\n", n, ndev, lanes);
     return 0;
 }

@@ -16,7 +16,7 @@ CFLAGS = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I",
 
 def test_header_is_plain_c99(tmp_path):
     tu = tmp_path / "only_header.c"
-    tu.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 1 ? 0 : 1; }\n')
+    tu.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 2 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(tu)], check=True)
 
 
@@ -34,8 +34,10 @@ def test_c_client_compiles_and_links_without_cxx_or_torch(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [0, 1, 1000])
-def test_c_client_reproduces_the_oracle(tmp_path, n):
+@pytest.mark.parametrize("n,lanes", [(0, 1), (1, 1), (1000, 1), (1000, 3), (2, 3), (70001, 4)])
+def test_c_client_reproduces_the_oracle(tmp_path, n, lanes):
+    """lanes > 1: the one-process, per-GPU-stream form (BASELINE configs[3]) from plain C -- one handle per device, every
+    shard enqueued before the first synchronisation, one hipStreamSynchronize per stream."""
     from modulationdetectioncnn_amd import synthetic_frames
     from oracle import oracle_np as O
     import modulationdetectioncnn_amd.build as b
@@ -47,9 +49,10 @@ def test_c_client_reproduces_the_oracle(tmp_path, n):
     np.concatenate([np.asarray(a, np.float32).ravel() for a in (ck, cb, dk, db)]).tofile(tmp_path / "w.bin")
     x = np.asarray(synthetic_frames(n, seed=11), np.float32)
     x.tofile(tmp_path / "x.bin")
-    r = subprocess.run([str(exe), str(tmp_path / "w.bin"), str(tmp_path / "x.bin"), str(n), str(tmp_path / "out.bin")],
+    r = subprocess.run([str(exe), str(tmp_path / "w.bin"), str(tmp_path / "x.bin"), str(n), str(tmp_path / "out.bin"), "3", str(lanes)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
+    assert f"{lanes} stream(s)" in r.stdout
     raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint8)
     probs = raw[: n * 12].view(np.float32).reshape(n, 3)
     labels = raw[n * 12:].view(np.int32)
