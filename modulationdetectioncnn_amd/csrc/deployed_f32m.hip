@@ -40,7 +40,6 @@ namespace mdc {
 namespace {
 
 constexpr int kC = 3;
-constexpr int kHead = 64;                 // conv taps + biases, padded (deployed_pack's layout)
 
 template <int F, bool U8, int RING = 0>
 struct F32mGeom {

@@ -45,7 +45,6 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // position block (11 outputs) x 16-channel chunk (conv2 weights of the chunk, 30 KB, staged
 // in LDS and shared by the 4 waves) x 13 padded positions x 2 rows x [1 conv1 + 60 conv2 MFMAs].
 // ------------------------------------------------------------------------------------
-constexpr int kP = 11;                 // output positions per block (batch form; the small-batch forms use 3 and 1)
 constexpr int kChunk = 16;             // channels per chunk
 constexpr int kNChunk = kC1 / kChunk;  // 16
 constexpr int kWChunkFloats = 2 * 3 * 5 * 4 * 64;   // [h][j][ot][r][lane] = 7680

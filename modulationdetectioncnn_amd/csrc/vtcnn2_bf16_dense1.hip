@@ -309,22 +309,34 @@ __global__ __launch_bounds__(64) void vt_dense1_bf16_small_kernel(const unsigned
     const unsigned short* ap = feat + ar * (long)kFeat + fg * 8;
     const unsigned short* bp = w1t + (long)(col0 + fr) * kBK + fg * 8;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int kU = 5;                                     // K-tiles per iteration: 20 fragment loads in flight
-    static_assert(kNT % kU == 0, "unroll must divide the K-tile count");
-    for (int t0 = 0; t0 < kNT; t0 += kU) {
-        bf16x8 af[kU][2], bfr[kU][2];
+    // software pipeline over blocks of kU K-tiles, two register sets: the 20 fragment loads of block i+1 are in flight
+    // while the 10 MFMAs of block i issue (the MFMA chain is the same: K-tiles in ascending order into one accumulator)
+    constexpr int kU = 5, kBlocks = kNT / kU;
+    static_assert(kNT % kU == 0 && kBlocks % 2 == 1, "blocks: an even count in the loop, the last one drained after it");
+    bf16x8 a0[kU][2], b0[kU][2], a1[kU][2], b1[kU][2];
+    auto load = [&](bf16x8 (&af)[kU][2], bf16x8 (&bfr)[kU][2], int blk) {
 #pragma unroll
         for (int u = 0; u < kU; ++u)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                af[u][ks] = *reinterpret_cast<const bf16x8*>(ap + (t0 + u) * kBK + ks * 32);
-                bfr[u][ks] = *reinterpret_cast<const bf16x8*>(bp + (long)(t0 + u) * (kBN * kBK) + ks * 32);
+                af[u][ks] = *reinterpret_cast<const bf16x8*>(ap + (blk * kU + u) * kBK + ks * 32);
+                bfr[u][ks] = *reinterpret_cast<const bf16x8*>(bp + (long)(blk * kU + u) * (kBN * kBK) + ks * 32);
             }
+    };
+    auto mma = [&](const bf16x8 (&af)[kU][2], const bf16x8 (&bfr)[kU][2]) {
 #pragma unroll
         for (int u = 0; u < kU; ++u)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][ks], bfr[u][ks], acc, 0, 0, 0);
+    };
+    load(a0, b0, 0);
+    for (int blk = 0; blk < kBlocks - 1; blk += 2) {
+        load(a1, b1, blk + 1);
+        mma(a0, b0);
+        load(a0, b0, blk + 2);
+        mma(a1, b1);
     }
+    mma(a0, b0);
     const int col = col0 + fr;
     const float bias = c1[col];
 #pragma unroll
@@ -334,7 +346,9 @@ __global__ __launch_bounds__(64) void vt_dense1_bf16_small_kernel(const unsigned
     }
 }
 
-constexpr long kSmallBatch = 64;       // frames up to which the per-wave kernel is used
+// frames up to which the per-wave kernel is used: 16 x n/16 waves of 16 x 16 outputs beat the 256-row tiles (one
+// work-group per 256 frames, 178 us whatever the batch) up to about 2,048 frames (tools/latency.py: 260 vs 296 us there)
+constexpr long kSmallBatch = 2048;
 
 }  // namespace
 

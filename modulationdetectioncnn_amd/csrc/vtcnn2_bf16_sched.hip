@@ -79,7 +79,10 @@ struct SchedState {
 };
 
 // conv2 MFMA number I (0..19) of tap J: channel block CT = 1 - I/10, half BB = (I/5)%2, output tile OT = I%5
-template <int SP, int J, int I>
+// PAD: the MFMA opens a block at a control-flow merge or split (range form: loop header, loop exit, the early exit of
+// the ranges 0 .. 9 after step S+13), where hipcc may
+// place AGPR copies (v_accvgpr_mov) of the accumulator right in front of it: two wait states inside the asm block
+template <int SP, int J, int I, bool PAD = false>
 __device__ __forceinline__ void sch_tap(SchedState& st, f32x4 (&acc)[5]) {
     constexpr int CT = 1 - I / 10, BB = (I / 5) % 2, OT = I % 5;
     constexpr int IDX = ((CT * 3 + J) * 2 + BB) * 5 + OT;
@@ -87,6 +90,9 @@ __device__ __forceinline__ void sch_tap(SchedState& st, f32x4 (&acc)[5]) {
     if constexpr (J == 0 && I < 5) {      // first MFMA of output v+2: C = bias (early-clobber: D must not alias an input)
         if constexpr (IDX < kNV) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "a"(st.bias[OT]));
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&a"(acc[OT]) : "a"(st.Wa[IDX - kNV]), "v"(b), "a"(st.bias[OT]));
+    } else if constexpr (PAD) {
+        static_assert(IDX >= kNV, "padded form written for the AGPR-resident fragments only");
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kNV]), "v"(b));
     } else {
         if constexpr (IDX < kNV) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b));
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kNV]), "v"(b));
@@ -112,8 +118,10 @@ __device__ __forceinline__ void sch_packop(SchedState& st) {
 //   5 no conv1 (operand prep, 2 MFMAs, pack)                      6 all of 2, 3, 5
 //   7 no feature stores (finish VALU kept)   8 no ds_writes   9 no reads of the partials
 //   10 no pack VALU (conv1 kept)             11 no operand loads / prep
-template <int V12, bool FIRST, bool LAST, int ABL>
-__device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned short* fbase, f32x4 (&acc)[3][5]) {
+// RANGE (small batches, see vt_conv_bf16_sched_kernel): the step belongs to a work-group that owns only the output
+// positions >= wlo of its frame group; outputs below wlo are computed from incomplete taps and must not be stored.
+template <int V12, bool FIRST, bool LAST, int ABL, bool RANGE = false>
+__device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned short* fbase, f32x4 (&acc)[3][5], int wlo = 0) {
     constexpr int PAR = V12 & 1, PN = 1 - PAR;
     constexpr int R1 = (V12 + 1) & 3, S0 = ((V12 + 1) >> 2) % 3, SN = (S0 + 1) % 3;      // position v+1 in its chunk; slots
     // operand loads: v = 4c+1 fetches entries (2c+2, 2c+3) = L0 of chunk c+1; v = 4c+3 entries (2c+3, 2c+4) = L1 of chunk c+1
@@ -129,7 +137,7 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
 #define FIN(K) do { if (!FIRST && kFin) sch_fin<K>(st, ft, fo); } while (0)
 #define PREP(I) do { if (!LAST && kC1 && ABL != 11) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST && kC1) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
-#define ST(W) do { if (!FIRST && kFin) { if (ABL == 7) asm volatile("" ::"v"(fo.o0), "v"(fo.o1), "v"(fo.tt)); else sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
+#define ST(W) do { if (!FIRST && kFin) { if (ABL == 7) asm volatile("" ::"v"(fo.o0), "v"(fo.o1), "v"(fo.tt)); else if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
 #define WR(OT) do { if (kExch && ABL != 8) sch_part_write<PAR, OT>(st, a2[OT]); } while (0)
 #define PK(N) do { if (!LAST && kC1 && ABL != 10) sch_packop<PN, N>(st); } while (0)
 #define RD(R) do { if (kExch && ABL != 9) sch_red_load1<PAR, R>(st); } while (0)
@@ -142,7 +150,7 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
         asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
     sch_wait_lds(st);      // partial(v-1) and any operand words: read during T0 of the previous step
     // ---- T2: tap 2 -> a2 complete.  gaps: finish of output v-1 (F0..F16); the conv1 operand dwords of v+1 in the last four
-    sch_tap<PAR, 2, 0>(st, a2); FIN(0);
+    sch_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); FIN(0);
     sch_tap<PAR, 2, 1>(st, a2); FIN(1);
     sch_tap<PAR, 2, 2>(st, a2); FIN(2);
     sch_tap<PAR, 2, 3>(st, a2); FIN(3);
@@ -221,7 +229,13 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
 #undef HANDOFF
 }
 
-template <int ABL, bool U8 = false>
+// RANGE = true (small batches: a single window is ONE 16-frame group, i.e. one work-group walking 130 dependent steps
+// on one CU while 255 idle): the group's 132 output positions are cut into 11 ranges on blockIdx.y.  Work-group r runs
+// steps 12r .. 12r+13 (the last one 120 .. 129 and the tail) with the unchanged step code -- a range starts on a multiple
+// of 12, where every register role (v mod 12) is that of step 0 -- and stores outputs 12r+2 .. 12r+13 (r = 0: from 0;
+// r = 10: 122 .. 131): the first two outputs a range completes lack the taps of the positions before it and belong to its
+// neighbour, which computes them with exactly the instruction sequence of the batch form -- the results are bit-identical.
+template <int ABL, bool U8 = false, bool RANGE = false>
 __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float* __restrict__ x, long n,
                                                                     const u32x4* __restrict__ wq, const u32x4* __restrict__ a1q,
                                                                     const float* __restrict__ b2, unsigned short* __restrict__ feat,
@@ -279,12 +293,15 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
     if (grp < ngroups)
         for (int k = 0; k < 4; ++k) sch_stage_write(k, stage_decode<U8>(stage_load<U8>(k, x, n, grp * 16, tid, hop2), tid, scale), n, grp * 16, img, tid);
     __syncthreads();
+    const int rng = RANGE ? (int)blockIdx.y : 0;      // position range of this work-group
+    const int S = 12 * rng;                           // its first step
+    const int wlo = rng ? S + 2 : 0;                  // its first output position
 
     int buf = 0;
     for (; grp < ngroups; grp += gridDim.x, buf ^= 1) {
         st.im_addr = img_lds + (buf * kSImgWords + lane * kS) * 4;
         unsigned short* fbase = feat + (grp * 16 + fs) * (long)(kW2 * kC2);
-        const long gnext = grp + gridDim.x;
+        const long gnext = RANGE ? ngroups : grp + gridDim.x;      // (a range work-group has no next group to stage)
         // outputs 0 and 1 never see a fresh MFMA: they start from the bias; acc[2] is step 0's fresh accumulator.
         // The copy is an MFMA (0 x 0 + bias), not `acc = bias`: hipcc turned the assignment into v_accvgpr_mov
         // instructions and sank two of them right in front of the asm MFMA that reads those AGPRs as its C operand
@@ -299,45 +316,63 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
             }
         }
 
-        // prologue: entries 0..2, conv1 of position 0 packed into Bf[0]
-        sch_load_even<0>(st, st.im_addr);
-        sch_load_odd(st, st.im_addr + 8);
+        // prologue: entries 0..2 (of the range's first chunk), conv1 of position S packed into Bf[0]
+        sch_load_even<0>(st, st.im_addr + (S >> 2) * 16);
+        sch_load_odd(st, st.im_addr + (S >> 2) * 16 + 8);
         sch_wait_lds(st);
         sch_conv1_mfma<0, 0, 0>(st); sch_conv1_mfma<0, 0, 1>(st);
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(st.X[0]), "+v"(st.X[1]));
         [&]<int... N>(std::integer_sequence<int, N...>) { (sch_packop<0, N>(st), ...); }(std::make_integer_sequence<int, 32>{});
         asm volatile("s_nop 1");
 
-        sch_step<0, true, false, ABL>(st, 0, q, fbase, acc);
-        int v = 1;
+        sch_step<0, true, false, ABL, RANGE>(st, S, q, fbase, acc, wlo);
+        // batch form: 10 x 12 steps (v = 1 .. 120), then 121 .. 129.  range form: one pass of the same 12-step body
+        // (S+1 .. S+12) and step S+13 for the ranges 0 .. 9, none for the last one (120 was its first step)
+        const int iters = RANGE ? (rng < 10 ? 1 : 0) : 10;
+        int v = S + 1;
         typename StageRaw<U8>::type sv{};
-        for (int it = 0; it < 10; ++it, v += 12) {     // v = 1 .. 120
+        for (int it = 0; it < iters; ++it, v += 12) {
             // next group's frames -> the other image buffer, a quarter per iteration; each quarter's global load is
             // issued one iteration (12 steps) before its conversion and LDS writes
-            if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, stage_decode<U8>(sv, tid, scale), n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
-            if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load<U8>(it - 5, x, n, gnext * 16, tid, hop2);
-            sch_step<1, false, false, ABL>(st, v + 0, q, fbase, acc);
-            sch_step<2, false, false, ABL>(st, v + 1, q, fbase, acc);
-            sch_step<3, false, false, ABL>(st, v + 2, q, fbase, acc);
-            sch_step<4, false, false, ABL>(st, v + 3, q, fbase, acc);
-            sch_step<5, false, false, ABL>(st, v + 4, q, fbase, acc);
-            sch_step<6, false, false, ABL>(st, v + 5, q, fbase, acc);
-            sch_step<7, false, false, ABL>(st, v + 6, q, fbase, acc);
-            sch_step<8, false, false, ABL>(st, v + 7, q, fbase, acc);
-            sch_step<9, false, false, ABL>(st, v + 8, q, fbase, acc);
-            sch_step<10, false, false, ABL>(st, v + 9, q, fbase, acc);
-            sch_step<11, false, false, ABL>(st, v + 10, q, fbase, acc);
-            sch_step<0, false, false, ABL>(st, v + 11, q, fbase, acc);
+            if constexpr (!RANGE) {
+                if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, stage_decode<U8>(sv, tid, scale), n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
+                if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load<U8>(it - 5, x, n, gnext * 16, tid, hop2);
+            }
+            sch_step<1, false, false, ABL, RANGE>(st, v + 0, q, fbase, acc, wlo);
+            sch_step<2, false, false, ABL, RANGE>(st, v + 1, q, fbase, acc, wlo);
+            sch_step<3, false, false, ABL, RANGE>(st, v + 2, q, fbase, acc, wlo);
+            sch_step<4, false, false, ABL, RANGE>(st, v + 3, q, fbase, acc, wlo);
+            sch_step<5, false, false, ABL, RANGE>(st, v + 4, q, fbase, acc, wlo);
+            sch_step<6, false, false, ABL, RANGE>(st, v + 5, q, fbase, acc, wlo);
+            sch_step<7, false, false, ABL, RANGE>(st, v + 6, q, fbase, acc, wlo);
+            sch_step<8, false, false, ABL, RANGE>(st, v + 7, q, fbase, acc, wlo);
+            sch_step<9, false, false, ABL, RANGE>(st, v + 8, q, fbase, acc, wlo);
+            sch_step<10, false, false, ABL, RANGE>(st, v + 9, q, fbase, acc, wlo);
+            sch_step<11, false, false, ABL, RANGE>(st, v + 10, q, fbase, acc, wlo);
+            sch_step<0, false, false, ABL, RANGE>(st, v + 11, q, fbase, acc, wlo);
         }
-        sch_step<1, false, false, ABL>(st, 121, q, fbase, acc);
-        sch_step<2, false, false, ABL>(st, 122, q, fbase, acc);
-        sch_step<3, false, false, ABL>(st, 123, q, fbase, acc);
-        sch_step<4, false, false, ABL>(st, 124, q, fbase, acc);
-        sch_step<5, false, false, ABL>(st, 125, q, fbase, acc);
-        sch_step<6, false, false, ABL>(st, 126, q, fbase, acc);
-        sch_step<7, false, false, ABL>(st, 127, q, fbase, acc);
-        sch_step<8, false, false, ABL>(st, 128, q, fbase, acc);
-        sch_step<9, false, true, ABL>(st, 129, q, fbase, acc);
+        const int vt = RANGE ? v : 121;      // S + 13 for the ranges 0 .. 9
+        sch_step<1, false, false, ABL, RANGE>(st, vt, q, fbase, acc, wlo);
+        if constexpr (RANGE) {
+            if (rng < 10) {      // finish of output S+13; the accumulators of S+14, S+15 are dropped
+                FinOut fo;
+                sch_wait_lds(st);
+                sch_fin_all(st, fo);
+                sch_store<0>(fo, fbase, vt, q, st.gs);
+                sch_store<1>(fo, fbase, vt, q, st.gs);
+                asm volatile("s_nop 7\n\ts_nop 7" ::"a"(acc[0][0]), "a"(acc[1][0]), "a"(acc[2][0]));      // in-flight MFMA results land before the registers die
+                __syncthreads();
+                continue;
+            }
+        }
+        sch_step<2, false, false, ABL, RANGE>(st, 122, q, fbase, acc, wlo);
+        sch_step<3, false, false, ABL, RANGE>(st, 123, q, fbase, acc, wlo);
+        sch_step<4, false, false, ABL, RANGE>(st, 124, q, fbase, acc, wlo);
+        sch_step<5, false, false, ABL, RANGE>(st, 125, q, fbase, acc, wlo);
+        sch_step<6, false, false, ABL, RANGE>(st, 126, q, fbase, acc, wlo);
+        sch_step<7, false, false, ABL, RANGE>(st, 127, q, fbase, acc, wlo);
+        sch_step<8, false, false, ABL, RANGE>(st, 128, q, fbase, acc, wlo);
+        sch_step<9, false, true, ABL, RANGE>(st, 129, q, fbase, acc, wlo);
         // tail: finish 129, then outputs 130 and 131 (complete as they are: only zero padding beyond).
         // step 129 (v%3 == 0) left output 130 in acc[1] and output 131 in acc[2].
         auto finish_store = [&](int w) {
@@ -417,14 +452,18 @@ int vtcnn2_bf16_pack_sched(mdc_model* m) {
 int vtcnn2_bf16_conv_sched(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2, float scale) {
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-    if (hop2 > 0) {      // raw uint8 I/Q straight into the staging
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_sched_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
-        hipLaunchKernelGGL((vt_conv_bf16_sched_kernel<0, true>), dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
-                           static_cast<const u32x4*>(m->d_pack[6]), static_cast<const u32x4*>(m->d_pack[7]),
-                           static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2, scale);
-        MDC_HIP(hipGetLastError());
-        return MDC_OK;
+#define MDC_LAUNCH_SCHED_V(U, R, GRID) do { \
+    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_sched_kernel<0, U, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
+    hipLaunchKernelGGL((vt_conv_bf16_sched_kernel<0, U, R>), GRID, dim3(256), kSchedLds, s, x, (long)n, \
+                       static_cast<const u32x4*>(m->d_pack[6]), static_cast<const u32x4*>(m->d_pack[7]), \
+                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2 > 0 ? hop2 : 256L, scale); \
+    MDC_HIP(hipGetLastError()); return MDC_OK; } while (0)
+    if (n <= kConvRangeFrames) {      // small batch: the group's positions over 11 work-groups (results identical)
+        if (hop2 > 0) MDC_LAUNCH_SCHED_V(true, true, dim3((unsigned)ngroups, 11));
+        else MDC_LAUNCH_SCHED_V(false, true, dim3((unsigned)ngroups, 11));
     }
+    if (hop2 > 0) MDC_LAUNCH_SCHED_V(true, false, dim3(grid));      // raw uint8 I/Q straight into the staging
+#undef MDC_LAUNCH_SCHED_V
 #define MDC_LAUNCH_SCHED(A) do { \
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_sched_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
     hipLaunchKernelGGL(vt_conv_bf16_sched_kernel<A>, dim3(grid), dim3(256), kSchedLds, s, x, (long)n, \

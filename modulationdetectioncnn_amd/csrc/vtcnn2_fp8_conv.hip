@@ -55,13 +55,18 @@ struct Fp8State {
 };
 
 // conv2 MFMA of tap J, output tile OT (the first one of an output, J == 0, takes the bias as C)
-template <int SP, int J, int OT>
+// PAD (range form): two wait states in front of an MFMA that opens a block at a control-flow merge / split, where hipcc
+// may put AGPR copies of the accumulator (vtcnn2_bf16_sched.hip, sch_tap)
+template <int SP, int J, int OT, bool PAD = false>
 __device__ __forceinline__ void f8_tap(Fp8State& st, f32x4 (&acc)[5]) {
     constexpr int IDX = J * 5 + OT;
     const u32x8 b = u32x8{st.Bf[SP][0], st.Bf[SP][1], st.Bf[SP][2], st.Bf[SP][3], st.Bf[SP][4], st.Bf[SP][5], st.Bf[SP][6], st.Bf[SP][7]};
     if constexpr (J == 0) {
         if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "a"(st.bias[OT]), "v"(st.one));
         else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "a"(st.bias[OT]), "v"(st.one));
+    } else if constexpr (PAD) {
+        if constexpr (IDX < kF8NV) asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "v"(st.one));
+        else asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "v"(st.one));
     } else {
         if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "v"(st.one));
         else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "v"(st.one));
@@ -85,8 +90,9 @@ __device__ __forceinline__ void f8_cvt(Fp8State& st) {
 }
 
 // One position step: 15 conv2 MFMAs + 2 conv1 MFMAs, every gap 32 cycles (2 VALU, or 1 VALU + 1 LDS, ride for free).
-template <int V12, bool FIRST, bool LAST>
-__device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned short* fbase, f32x4 (&acc)[3][5]) {
+// RANGE / wlo: the position-range form for small batches (vtcnn2_bf16_sched.hip): outputs below wlo are not stored
+template <int V12, bool FIRST, bool LAST, bool RANGE = false>
+__device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned short* fbase, f32x4 (&acc)[3][5], int wlo = 0) {
     constexpr int PAR = V12 & 1, PN = 1 - PAR;
     constexpr int R1 = (V12 + 1) & 3, S0 = ((V12 + 1) >> 2) % 3, SN = (S0 + 1) % 3;
     constexpr bool kLoadEven = (V12 & 3) == 1 && !LAST, kLoadOdd = (V12 & 3) == 3 && !LAST;
@@ -100,7 +106,7 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
 #define FIN(K) do { if (!FIRST) sch_fin<K>(st, ft, fo); } while (0)
 #define PREP(I) do { if (!LAST) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
-#define ST(W) do { if (!FIRST) sch_store<W>(fo, fbase, v - 1, q, st.gs); } while (0)
+#define ST(W) do { if (!FIRST) { if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
 #define WR(OT) sch_part_write<PAR, OT>(st, a2[OT])
 #define RL(N) do { if (!LAST) f8_relu<N>(st); } while (0)
 #define CV(K) do { if (!LAST) f8_cvt<PN, K>(st); } while (0)
@@ -111,7 +117,7 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
         asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
     sch_wait_lds(st);
     // ---- T2: tap 2 -> a2 complete; finish of output v-1, conv1 operand dwords of v+1
-    f8_tap<PAR, 2, 0>(st, a2); FIN(0); FIN(1); FIN(2); FIN(3);
+    f8_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); FIN(0); FIN(1); FIN(2); FIN(3);
     f8_tap<PAR, 2, 1>(st, a2); FIN(4); FIN(5); FIN(6); FIN(7);
     f8_tap<PAR, 2, 2>(st, a2); FIN(8); FIN(9); FIN(10); FIN(11);
     f8_tap<PAR, 2, 3>(st, a2); FIN(12); FIN(13); FIN(14); FIN(15); PREP(0); PREP(1);
@@ -143,7 +149,9 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
 #undef HANDOFF
 }
 
-template <bool U8>
+// RANGE: grid (groups, 11), work-group (g, r) runs steps 12r .. 12r+13 (r = 10: 120 .. 129 and the tail) and stores the
+// outputs 12r+2 .. 12r+13 (r = 0: from 0; r = 10: 122 .. 131) -- see vt_conv_bf16_sched_kernel
+template <bool U8, bool RANGE = false>
 __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __restrict__ x, long n,
                                                              const u32x8* __restrict__ wq, const u32x4* __restrict__ a1q,
                                                              const float* __restrict__ b2, unsigned short* __restrict__ feat,
@@ -196,12 +204,15 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     if (grp < ngroups)
         for (int k = 0; k < 4; ++k) sch_stage_write(k, stage_decode<U8>(stage_load<U8>(k, x, n, grp * 16, tid, hop2), tid, scale), n, grp * 16, img, tid);
     __syncthreads();
+    const int rng = RANGE ? (int)blockIdx.y : 0;
+    const int S = 12 * rng;
+    const int wlo = rng ? S + 2 : 0;
 
     int buf = 0;
     for (; grp < ngroups; grp += gridDim.x, buf ^= 1) {
         st.im_addr = img_lds + (buf * kSImgWords + lane * kS) * 4;
         unsigned short* fbase = feat + (grp * 16 + fs) * (long)(kW2 * kC2);
-        const long gnext = grp + gridDim.x;
+        const long gnext = RANGE ? ngroups : grp + gridDim.x;
         // accumulators of outputs 0 and 1 start from the bias: an MFMA (0 x 0 + bias), never a compiler AGPR copy
         f32x4 acc[3][5];
         {
@@ -212,9 +223,9 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %2" : "=&a"(acc[1][b]) : "v"(zero), "a"(st.bias[b]));
             }
         }
-        // prologue: entries 0..2, conv1 of position 0 packed into Bf[0]
-        sch_load_even<0>(st, st.im_addr);
-        sch_load_odd(st, st.im_addr + 8);
+        // prologue: entries 0..2 of the range's first chunk, conv1 of position S packed into Bf[0]
+        sch_load_even<0>(st, st.im_addr + (S >> 2) * 16);
+        sch_load_odd(st, st.im_addr + (S >> 2) * 16 + 8);
         sch_wait_lds(st);
         sch_conv1_mfma<0, 0, 0>(st); sch_conv1_mfma<0, 0, 1>(st);
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(st.X[0]), "+v"(st.X[1]));
@@ -222,34 +233,52 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
         [&]<int... K>(std::integer_sequence<int, K...>) { (f8_cvt<0, K>(st), ...); }(std::make_integer_sequence<int, 16>{});
         asm volatile("s_nop 1");
 
-        f8_step<0, true, false>(st, 0, q, fbase, acc);
-        int v = 1;
+        f8_step<0, true, false, RANGE>(st, S, q, fbase, acc, wlo);
+        // batch form: 10 x 12 steps (v = 1 .. 120), then 121 .. 129; range form: one pass of the 12-step body and step
+        // S+13 for the ranges 0 .. 9, none for the last one
+        const int iters = RANGE ? (rng < 10 ? 1 : 0) : 10;
+        int v = S + 1;
         typename StageRaw<U8>::type sv{};
-        for (int it = 0; it < 10; ++it, v += 12) {     // v = 1 .. 120
-            if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, stage_decode<U8>(sv, tid, scale), n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
-            if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load<U8>(it - 5, x, n, gnext * 16, tid, hop2);
-            f8_step<1, false, false>(st, v + 0, q, fbase, acc);
-            f8_step<2, false, false>(st, v + 1, q, fbase, acc);
-            f8_step<3, false, false>(st, v + 2, q, fbase, acc);
-            f8_step<4, false, false>(st, v + 3, q, fbase, acc);
-            f8_step<5, false, false>(st, v + 4, q, fbase, acc);
-            f8_step<6, false, false>(st, v + 5, q, fbase, acc);
-            f8_step<7, false, false>(st, v + 6, q, fbase, acc);
-            f8_step<8, false, false>(st, v + 7, q, fbase, acc);
-            f8_step<9, false, false>(st, v + 8, q, fbase, acc);
-            f8_step<10, false, false>(st, v + 9, q, fbase, acc);
-            f8_step<11, false, false>(st, v + 10, q, fbase, acc);
-            f8_step<0, false, false>(st, v + 11, q, fbase, acc);
+        for (int it = 0; it < iters; ++it, v += 12) {
+            if constexpr (!RANGE) {
+                if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, stage_decode<U8>(sv, tid, scale), n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
+                if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load<U8>(it - 5, x, n, gnext * 16, tid, hop2);
+            }
+            f8_step<1, false, false, RANGE>(st, v + 0, q, fbase, acc, wlo);
+            f8_step<2, false, false, RANGE>(st, v + 1, q, fbase, acc, wlo);
+            f8_step<3, false, false, RANGE>(st, v + 2, q, fbase, acc, wlo);
+            f8_step<4, false, false, RANGE>(st, v + 3, q, fbase, acc, wlo);
+            f8_step<5, false, false, RANGE>(st, v + 4, q, fbase, acc, wlo);
+            f8_step<6, false, false, RANGE>(st, v + 5, q, fbase, acc, wlo);
+            f8_step<7, false, false, RANGE>(st, v + 6, q, fbase, acc, wlo);
+            f8_step<8, false, false, RANGE>(st, v + 7, q, fbase, acc, wlo);
+            f8_step<9, false, false, RANGE>(st, v + 8, q, fbase, acc, wlo);
+            f8_step<10, false, false, RANGE>(st, v + 9, q, fbase, acc, wlo);
+            f8_step<11, false, false, RANGE>(st, v + 10, q, fbase, acc, wlo);
+            f8_step<0, false, false, RANGE>(st, v + 11, q, fbase, acc, wlo);
         }
-        f8_step<1, false, false>(st, 121, q, fbase, acc);
-        f8_step<2, false, false>(st, 122, q, fbase, acc);
-        f8_step<3, false, false>(st, 123, q, fbase, acc);
-        f8_step<4, false, false>(st, 124, q, fbase, acc);
-        f8_step<5, false, false>(st, 125, q, fbase, acc);
-        f8_step<6, false, false>(st, 126, q, fbase, acc);
-        f8_step<7, false, false>(st, 127, q, fbase, acc);
-        f8_step<8, false, false>(st, 128, q, fbase, acc);
-        f8_step<9, false, true>(st, 129, q, fbase, acc);
+        const int vt = RANGE ? v : 121;
+        f8_step<1, false, false, RANGE>(st, vt, q, fbase, acc, wlo);
+        if constexpr (RANGE) {
+            if (rng < 10) {      // finish of output S+13; the accumulators of S+14, S+15 are dropped
+                FinOut fo;
+                sch_wait_lds(st);
+                sch_fin_all(st, fo);
+                sch_store<0>(fo, fbase, vt, q, st.gs);
+                sch_store<1>(fo, fbase, vt, q, st.gs);
+                asm volatile("s_nop 7\n\ts_nop 7" ::"a"(acc[0][0]), "a"(acc[1][0]), "a"(acc[2][0]));
+                __syncthreads();
+                continue;
+            }
+        }
+        f8_step<2, false, false, RANGE>(st, 122, q, fbase, acc, wlo);
+        f8_step<3, false, false, RANGE>(st, 123, q, fbase, acc, wlo);
+        f8_step<4, false, false, RANGE>(st, 124, q, fbase, acc, wlo);
+        f8_step<5, false, false, RANGE>(st, 125, q, fbase, acc, wlo);
+        f8_step<6, false, false, RANGE>(st, 126, q, fbase, acc, wlo);
+        f8_step<7, false, false, RANGE>(st, 127, q, fbase, acc, wlo);
+        f8_step<8, false, false, RANGE>(st, 128, q, fbase, acc, wlo);
+        f8_step<9, false, true, RANGE>(st, 129, q, fbase, acc, wlo);
         // tail: finish 129, then outputs 130 and 131 (complete as they are: only zero padding beyond).
         // step 129 (v%3 == 0) left output 130 in acc[1] and output 131 in acc[2].
         auto finish_store = [&](int w) {
@@ -367,17 +396,20 @@ int vtcnn2_fp8_pack(mdc_model* m) {
 int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2, float scale) {
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-    if (hop2 > 0) {      // raw uint8 I/Q straight into the staging
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
-        hipLaunchKernelGGL(vt_conv_fp8_kernel<true>, dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
-                           static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]),
-                           static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2, scale);
+#define MDC_LAUNCH_F8(U, R, GRID) do { \
+    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<U, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
+    hipLaunchKernelGGL((vt_conv_fp8_kernel<U, R>), GRID, dim3(256), kSchedLds, s, x, (long)n, \
+                       static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]), \
+                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2 > 0 ? hop2 : 256L, scale); } while (0)
+    // hop2 > 0: raw uint8 I/Q straight into the staging.  Small batches: the position-range form (results identical)
+    if (n <= kConvRangeFrames) {
+        if (hop2 > 0) MDC_LAUNCH_F8(true, true, dim3((unsigned)ngroups, 11));
+        else MDC_LAUNCH_F8(false, true, dim3((unsigned)ngroups, 11));
     } else {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds));
-        hipLaunchKernelGGL(vt_conv_fp8_kernel<false>, dim3(grid), dim3(256), kSchedLds, s, x, (long)n,
-                           static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]),
-                           static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), 256L, 0.f);
+        if (hop2 > 0) MDC_LAUNCH_F8(true, false, dim3(grid));
+        else MDC_LAUNCH_F8(false, false, dim3(grid));
     }
+#undef MDC_LAUNCH_F8
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

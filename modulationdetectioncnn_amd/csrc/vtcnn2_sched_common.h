@@ -15,6 +15,10 @@ namespace {
 
 constexpr int kS = 140;                   // image words per lane: entries 0..67 (66, 67 zero) + 4 pad
 constexpr int kSImgWords = 64 * kS;       // [lane][kS] per buffer
+// Batches up to this size run the conv kernels' position-range form: 11 work-groups per 16-frame group, each walking 14 of
+// the 130 steps (a group is otherwise ONE work-group on one CU for ~100 us while the chip idles).  Whole forward, bf16,
+// range vs batch form: 60 vs 119 us at n = 1, 163 vs 189 us at 1,024, 284 vs 260 us at 2,048 (tools/latency.py)
+constexpr long kConvRangeFrames = 1024;
 constexpr size_t kSchedLds = (size_t)2 * kSImgWords * 4 + (size_t)2 * kPartFloats * 4;      // 112,640 B
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;

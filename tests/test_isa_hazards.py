@@ -11,22 +11,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
-def test_sched_kernel_has_no_store_vs_mfma_hazard():
+@pytest.mark.parametrize("inst", ["ILi0ELb0ELb0", "ILi0ELb1ELb0", "ILi0ELb0ELb1", "ILi0ELb1ELb1"])      # <ABL 0, U8, RANGE>
+def test_sched_kernel_has_no_store_vs_mfma_hazard(inst):
+    """every shipped instantiation: f32 frames / raw bytes, batch form / position-range form (small batches)"""
     spec = importlib.util.spec_from_file_location("lint_async_hazards", os.path.join(ROOT, "tools", "lint_async_hazards.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
-    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_sched.hip"), "vt_conv_bf16_sched_kernelILi0")
+    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_sched.hip"), "vt_conv_bf16_sched_kernel" + inst)
     assert sum(1 for x in isa if x.startswith("v_mfma")) > 1000          # the kernel was found and is unrolled
     assert sum(1 for x in isa if x.startswith("global_store")) >= 40
     assert lint.lint(isa) == []
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
-def test_fp8_kernel_has_no_store_vs_mfma_hazard():
+@pytest.mark.parametrize("inst", ["ILb0ELb0", "ILb1ELb0", "ILb0ELb1", "ILb1ELb1"])      # <U8, RANGE>
+def test_fp8_kernel_has_no_store_vs_mfma_hazard(inst):
     spec = importlib.util.spec_from_file_location("lint_async_hazards", os.path.join(ROOT, "tools", "lint_async_hazards.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
-    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_fp8_conv.hip"), "vt_conv_fp8_kernel")
+    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_fp8_conv.hip"), "vt_conv_fp8_kernel" + inst)
     assert sum(1 for x in isa if x.startswith("v_mfma_scale")) > 300
     assert lint.lint(isa) == []
 
@@ -41,5 +44,9 @@ def test_lint_flags_the_pattern():
     assert lint.lint(ok) == []
     mov = ["v_accvgpr_mov_b32 a200, a160", "v_mfma_f32_16x16x32_bf16 a[200:203], a[80:83], v[180:183], a[200:203]"]
     assert len(lint.lint(mov)) == 1
+    padded = ["v_accvgpr_mov_b32 a200, a160", "s_nop 1", "v_mfma_f32_16x16x32_bf16 a[200:203], a[80:83], v[180:183], a[200:203]"]
+    assert lint.lint(padded) == []
+    short = ["v_accvgpr_mov_b32 a200, a160", "s_nop 0", "v_mfma_f32_16x16x32_bf16 a[200:203], a[80:83], v[180:183], a[200:203]"]
+    assert len(lint.lint(short)) == 1
     waited = ["ds_write_b128 v10, v[20:23]", "s_waitcnt lgkmcnt(0)", "v_mfma_f32_16x16x16_bf16 v[20:23], v[1:2], v[3:4], 0"]
     assert lint.lint(waited) == []

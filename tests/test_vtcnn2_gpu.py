@@ -174,15 +174,16 @@ def test_two_streams_share_one_model(dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
 def test_small_batch_forms_are_bit_identical_to_the_batch_kernels(dtype):
-    """A single window (or a few) takes other launch forms -- one conv position per work-group in f32, a per-wave
-    dense1 tile in every dtype -- that run the same instruction sequence per output element: a frame's result must
+    """A single window (or a few) takes other launch forms -- one conv position per work-group in f32, a range of 12
+    positions per work-group in bf16 / fp8 (up to 1,024 frames), a per-wave dense1 tile in every dtype (up to 2,048)
+    -- that run the same instruction sequence per output element: a frame's result must
     not depend on how many frames it arrives with.  (The reference classifies one window per start pulse,
     cnn_test_latest1.sv:144-209.)"""
     m, _ = _model(11, dtype)
     x = synthetic_frames(5000, seed=31, device="cuda")
     big_p, big_l, _ = m.forward_device(x, batch_size=5000)            # batch kernels (n > 2,048)
     big_h = m.predict(x, tap="hidden", batch_size=5000)
-    for n in (1, 2, 15, 16, 17, 33, 64, 65, 300, 384, 385, 2048):      # every launch form and its boundaries
+    for n in (1, 2, 15, 16, 17, 33, 64, 65, 300, 384, 385, 1009, 1024, 1025, 2048, 2049):      # every launch form and its boundaries
         xs = x[:n].contiguous()
         p, l, _ = m.forward_device(xs)
         assert torch.equal(p, big_p[:n]) and torch.equal(l, big_l[:n]), (dtype, n)

@@ -61,16 +61,21 @@ def kernel_isa(src, kernel):
 def lint(isa):
     found = []
     # (b) a VALU write (hipcc pads v_accvgpr_mov/write -> MFMA only for its own MFMAs, not for asm ones) of a register
-    #     that one of the next two instructions, an MFMA, reads
+    #     that an MFMA reads fewer than two wait states later (an instruction = 1, s_nop N = N + 1)
     for i, ins in enumerate(isa):
         if ins.startswith(("v_accvgpr_mov", "v_accvgpr_write")):
             dst = ins.split()[1].rstrip(",")
+            waits = 0
             for j in range(i + 1, min(i + 3, len(isa))):
                 if isa[j].startswith("v_mfma") and re.search(r"\ba\[(\d+):(\d+)\]", isa[j]):
                     n = int(dst[1:])
                     for m in re.finditer(r"\ba\[(\d+):(\d+)\]", isa[j].split(",", 1)[1]):
                         if int(m.group(1)) <= n <= int(m.group(2)):
                             found.append((i, ins, isa[j]))
+                m = re.match(r"s_nop (\d+)", isa[j])
+                waits += int(m.group(1)) + 1 if m else 1
+                if waits >= 2:
+                    break
     # (a) store-like instruction vs a following VGPR-writing MFMA
     for i, ins in enumerate(isa):
         if ins.startswith(("global_store", "ds_write", "buffer_store", "scratch_store")):
@@ -89,7 +94,7 @@ def lint(isa):
 
 def main():
     src = os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_sched.hip")
-    kernel = sys.argv[2] if len(sys.argv) > 2 else "vt_conv_bf16_sched_kernelILi0"
+    kernel = sys.argv[2] if len(sys.argv) > 2 else "vt_conv_bf16_sched_kernelILi0ELb0ELb0"
     isa = kernel_isa(src, kernel)
     found = lint(isa)
     n_mfma_v = sum(1 for x in isa if x.startswith("v_mfma") and x.split()[1].startswith("v"))
