@@ -282,6 +282,57 @@ def run_q612(filters, device, steps=10, warmup=3, n=1 << 20):
                                                         "from": "wall time incl. two small output allocations, one launch per step; HBM fraction reported, the bound is 64-bit integer VALU"}}
 
 
+def run_host_path(device, steps=4, warmup=1):
+    """Extra leg: the PCIe-INCLUSIVE rate -- frames in pageable host memory (the numpy array of cnn.py:198), results back
+    in host memory, through the library's streaming driver (mdc_predict_host: pinned ring, copy / compute / result
+    streams).  Never the headline `value`, which starts from HBM-resident input.  Every timed call gets a FRESH array
+    (the HIP runtime remembers host ranges it has pinned once; a caller's next batch is new memory).  Beside it: the same
+    call on memory the caller pinned, and the unpipelined form (torch .to(device) + forward + .cpu())."""
+    import time
+    import numpy as np
+    import torch
+    from modulationdetectioncnn_amd import synthetic_frames
+
+    def timed(fn, fresh, k, w):
+        ts = []
+        for i in range(w + k):
+            a = fresh()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            fn(a)
+            torch.cuda.synchronize()
+            if i >= w:
+                ts.append(time.perf_counter() - t)
+            del a
+        return sum(ts) / len(ts)
+
+    rows = []
+    for name, n in (("vtcnn2-c11-bf16-n2^20", 1 << 20), ("deployed3-f32-n2^20", 1 << 20)):
+        m, _, _ = make_model(name, device)
+        x = synthetic_frames(n, seed=2016)                      # numpy, pageable
+        t_host = timed(lambda a: m.predict_host(a), x.copy, steps, warmup)
+
+        def plain(a):
+            p, l, _ = m.forward_device(torch.from_numpy(a).to(f"cuda:{device}"))
+            return p.cpu(), l.cpu()
+        t_plain = timed(plain, x.copy, steps, warmup)
+        xp = torch.from_numpy(x).pin_memory().numpy()
+        t_pinned = timed(lambda a: m.predict_host(a), lambda: xp, steps, warmup)
+        row = {"workload": name, "frames": n, "streaming_driver_frames_per_s": n / t_host, "ms": t_host * 1e3,
+               "input_gb_per_s": n * 1024 / t_host / 1e9, "caller_pinned_frames_per_s": n / t_pinned,
+               "unpipelined_frames_per_s": n / t_plain}
+        if name.startswith("deployed3"):
+            iq = np.random.default_rng(1).integers(0, 256, size=(1 << 22) * 256, dtype=np.uint8)
+            t_iq = timed(lambda a: m.predict_iq_u8(a, 0.02 / 127.5), iq.copy, steps, warmup)
+            row["raw_iq_u8_n2^22_frames_per_s"] = (1 << 22) / t_iq
+            del iq
+        rows.append(row)
+        del m, x, xp
+        torch.cuda.empty_cache()
+    return {"workload": "host-resident input and output (PCIe-inclusive; mdc_predict_host), fresh pageable numpy arrays unless noted",
+            "unit": "frames/s", "rows": rows}
+
+
 def metric_name(kind, filters, n):
     """BASELINE.json's metric string for the workloads it is quoted on (VT-CNN2 at batch 2^20); every other workload
     or batch size says what it is."""
@@ -379,6 +430,10 @@ def main(argv=None):
                                "unit": "us", "rows": latency.rows(device, sizes=(1, 16, 64, 4096), reps=100)})
             except Exception as e:
                 extras.append({"workload": "latency", "error": repr(e)})
+            try:      # numpy in, numpy out: what cnn.py:198 hands over (never the headline value)
+                extras.append(run_host_path(device))
+            except Exception as e:
+                extras.append({"workload": "host-resident input", "error": repr(e)})
             out["extra"] = extras
     if dist:
         dist.barrier()

@@ -167,6 +167,23 @@ int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, int6
                       float* probs_dev, int32_t* labels_dev,
                       void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
+/* test_Y_hat = model.predict(X_test, batch_size=batch_size)  (cnn.py:198, 237) when X_test lies in HOST memory -- a
+ * numpy array, or whatever buffer a cgo / JNI / N-API caller holds: the library's own driver in front of mdc_forward.
+ * Frames are copied into a pinned ring by a few host threads, DMA'd, computed and the results DMA'd back in three
+ * overlapping slots of chunk_frames frames (0 = 65,536) on the library's own streams, so the call runs at
+ * max(PCIe, kernel) rather than their sum; x_host that is already pinned (hipHostMalloc / hipHostRegister) is DMA'd
+ * from where it lies.  SYNCHRONOUS, like Keras' predict: returns when probs_host (n,C) f32 and labels_host (n) int32
+ * (each may be NULL) are complete.  Results are bit-identical to mdc_forward on the same frames, whatever the chunk.
+ * Staging buffers, streams and the workspace belong to the model (created on first use, freed by mdc_destroy); calls
+ * on one model are serialised.  Added in ABI 2 (additive). */
+int mdc_predict_host(mdc_model* m, const float* x_host, int64_t n, float* probs_host, int32_t* labels_host,
+                     int64_t chunk_frames);
+
+/* The same for raw uint8 I/Q in host memory (an SDR capture buffer, README.md:5): n windows, `hop` pairs apart, from
+ * iq_host (2*hop*(n-1) + 256 bytes) through mdc_forward_iq_u8 -- 2*hop bytes per window over PCIe instead of 1,024. */
+int mdc_predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int64_t hop, float scale,
+                           float* probs_host, int32_t* labels_host, int64_t chunk_frames);
+
 /* Measurement support (bench.py roofline leg): when on, mdc_forward brackets each kernel
  * launch with HIP events on the launch stream; mdc_profile_read synchronises on them and
  * returns the summed device time and launch count of kernel slot `slot` since the last

@@ -21,7 +21,7 @@ EXPORTS = [
     "mdc_finalize", "mdc_workspace_bytes", "mdc_forward", "mdc_set_profiling", "mdc_profile_slots",
     "mdc_profile_name", "mdc_profile_read", "mdc_profile_reset", "mdc_last_error", "mdc_destroy",
     "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax",
-    "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows",
+    "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8",
 ]
 ABI_VERSION = 2
 HOP_FRAME = 128
@@ -77,10 +77,12 @@ def lib() -> C.CDLL:
     L.mdc_forward_iq_u8.argtypes = [vp, vp, i64, i64, C.c_float, vp, vp, vp, sz, vp]
     L.mdc_confusion_binned.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.mdc_iq_u8_windows.argtypes = [vp, i64, i64, C.c_float, vp, vp]
+    L.mdc_predict_host.argtypes = [vp, vp, i64, vp, vp, i64]
+    L.mdc_predict_host_iq_u8.argtypes = [vp, vp, i64, i64, C.c_float, vp, vp, i64]
     for name in ("mdc_create", "mdc_num_layers", "mdc_layer_sizes", "mdc_set_weights", "mdc_finalize",
                  "mdc_forward", "mdc_set_profiling", "mdc_profile_slots", "mdc_profile_read", "mdc_profile_reset",
                  "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax", "mdc_forward_iq_u8",
-                 "mdc_confusion_binned", "mdc_iq_u8_windows"):
+                 "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8"):
         getattr(L, name).restype = i32
     if L.mdc_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libmdc.so ABI version {L.mdc_abi_version()} != {ABI_VERSION}; rebuild it")

@@ -23,7 +23,7 @@ LIB = os.path.join(HERE, "libmdc.so")
 ARCH = "gfx950"
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"),
-            "-I", CSRC, "-Wall", "-Wno-unused-function"]
+            "-I", CSRC, "-Wall", "-Wno-unused-function", "-pthread"]
 # (no -fno-exceptions: the C ABI catches std::bad_alloc & co. at the boundary and returns MDC_ENOMEM, mdc_api.hip)
 STAMP = os.path.join(OBJ, "flags.stamp")
 
@@ -81,7 +81,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     with open(STAMP, "w") as f:
         f.write(flag_key + "\n")
     if jobs or not _newer(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

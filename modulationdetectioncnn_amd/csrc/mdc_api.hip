@@ -51,17 +51,6 @@ ProfScope::~ProfScope() {
     }
 }
 
-// Device guard: the entry points run on the model's device and leave the caller's current device as they found it.
-struct DeviceScope {
-    int prev = -1, want;
-    bool ok = true;
-    explicit DeviceScope(int device) : want(device) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
-    }
-    ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
-};
-
 }  // namespace mdc
 
 using namespace mdc;
@@ -390,8 +379,21 @@ int mdc_profile_reset(mdc_model* m) {
     return MDC_OK;
 }
 
+int mdc_predict_host(mdc_model* m, const float* x_host, int64_t n, float* probs_host, int32_t* labels_host, int64_t chunk_frames) {
+    return guarded("mdc_predict_host", [&]() -> int { return predict_host(m, x_host, n, probs_host, labels_host, chunk_frames); });
+}
+
+int mdc_predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int64_t hop, float scale, float* probs_host,
+                           int32_t* labels_host, int64_t chunk_frames) {
+    return guarded("mdc_predict_host_iq_u8", [&]() -> int { return predict_host_iq_u8(m, iq_host, n, hop, scale, probs_host, labels_host, chunk_frames); });
+}
+
 void mdc_destroy(mdc_model* m) {
     if (!m) return;
+    {
+        DeviceScope dev(m->device);
+        host_ctx_free(m);
+    }
     for (void*& p : m->d_pack) if (p) { (void)hipFree(p); p = nullptr; }
     for (ProfSlot& ps : m->slots) for (hipEvent_t e : ps.ev) (void)hipEventDestroy(e);
     delete m;

@@ -77,6 +77,10 @@ struct mdc_model {
     bool profiling = false;
     std::vector<mdc::ProfSlot> slots;
     std::mutex prof_mu;
+
+    // host-buffer driver (host_path.hip): streams, pinned ring and device slots, created on first use; calls are serialised
+    void* host_ctx = nullptr;
+    std::mutex host_mu;
 };
 
 namespace mdc {
@@ -95,6 +99,25 @@ struct ProfScope {
 };
 
 int upload(mdc_model* m, int idx, const void* host, size_t bytes);
+
+// Device guard: the entry points run on the model's device and leave the caller's current device as they found it.
+struct DeviceScope {
+    int prev = -1, want;
+    bool ok = true;
+    explicit DeviceScope(int device) : want(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
+    }
+    ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+// ---- host-buffer driver: host_path.hip ----------------------------------------------------
+int predict_host(mdc_model* m, const float* x_host, int64_t n, float* probs_host, int32_t* labels_host, int64_t chunk_frames);
+int predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int64_t hop, float scale, float* probs_host, int32_t* labels_host,
+                       int64_t chunk_frames);
+void host_ctx_free(mdc_model* m);
 
 // ---- deployed (T1/T2): deployed.hip -------------------------------------------------
 int deployed_pack(mdc_model* m);

@@ -29,6 +29,9 @@ from .topology import Topology, synthetic_weights
 _KIND = {"deployed": _cabi.KIND_DEPLOYED, "vtcnn2": _cabi.KIND_VTCNN2, "cnnpy": _cabi.KIND_CNNPY}
 _DTYPE = {"f32": _cabi.F32, "fp32": _cabi.F32, "float32": _cabi.F32, "bf16": _cabi.BF16, "bfloat16": _cabi.BF16,
           "fp8": _cabi.FP8, "f16": _cabi.F16, "fp16": _cabi.F16, "float16": _cabi.F16}
+# slots of the host-buffer driver are at least this long (frames), whatever batch_size a Keras-style call passes
+HOST_MIN_CHUNK = 16384
+
 _TAP = {None: _cabi.TAP_NONE, "conv": _cabi.TAP_CONV, "flat": _cabi.TAP_FLAT, "dense": _cabi.TAP_DENSE,
         "hidden": _cabi.TAP_HIDDEN}
 
@@ -282,6 +285,26 @@ class VTCNN2:
                 ws.data_ptr() if ws is not None else None, ws_bytes, stream))
         return probs, labels, tap_out
 
+    def _host_chunk(self, batch_size) -> int:
+        """Keras' batch_size is a speed knob, not a result knob (results do not depend on it): the host-buffer driver
+        keeps its slots at least HOST_MIN_CHUNK frames long, whatever the caller's cnn.py:198 passes (1024 there)."""
+        return max(int(batch_size), HOST_MIN_CHUNK) if batch_size else 0
+
+    def predict_host(self, X: np.ndarray, batch_size: Optional[int] = None, want_probs: bool = True,
+                     want_labels: bool = True) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+        """numpy frames in, numpy (probs, labels) out through the library's own host-buffer driver (mdc_predict_host:
+        pinned ring, copy / compute / result streams overlapped).  Bit-identical to the device path."""
+        a = np.ascontiguousarray(np.asarray(X), dtype=np.float32)
+        if a.ndim != 3 or a.shape[1:] != (2, 128):
+            raise ValueError(f"expected input of shape (n,2,128); got {a.shape}")
+        n, Cn = a.shape[0], self.topology.classes
+        probs = np.empty((n, Cn), np.float32) if want_probs else None
+        labels = np.empty((n,), np.int32) if want_labels else None
+        _cabi.check(_cabi.lib().mdc_predict_host(self._engine(), a.ctypes.data, n,
+                                                 probs.ctypes.data if want_probs else None,
+                                                 labels.ctypes.data if want_labels else None, self._host_chunk(batch_size)))
+        return probs, labels
+
     def _run(self, X, batch_size, tap):
         torch = _torch()
         as_numpy = not isinstance(X, torch.Tensor)
@@ -300,13 +323,18 @@ class VTCNN2:
 
     def predict(self, X, batch_size: Optional[int] = None, tap: Optional[str] = None):
         """``model.predict(X, batch_size)``: (n,C) float32 softmax rows; with ``tap`` the named
-        intermediate layer of CNN.ipynb cell 17 instead.  Results do not depend on batch_size."""
+        intermediate layer of CNN.ipynb cell 17 instead.  Results do not depend on batch_size.  numpy in -> numpy out
+        (through the streaming host-buffer driver); torch-ROCm tensor in -> tensor out on torch's current stream."""
+        if tap is None and not isinstance(X, _torch().Tensor):
+            return self.predict_host(X, batch_size, want_labels=False)[0]
         as_numpy, probs, _labels, tap_out = self._run(X, batch_size, tap)
         out = tap_out if tap is not None else probs
         return out.cpu().numpy() if as_numpy else out
 
     def predict_classes(self, X, batch_size: Optional[int] = None):
         """Row-wise ``np.argmax`` of predict(X) (cnn.py:209: first maximum wins), int32 (n,)."""
+        if not isinstance(X, _torch().Tensor):
+            return self.predict_host(X, batch_size, want_probs=False)[1]
         as_numpy, _probs, labels, _ = self._run(X, batch_size, None)
         return labels.cpu().numpy() if as_numpy else labels
 
@@ -437,6 +465,13 @@ class VTCNN2:
         from .frontend import DEFAULT_SCALE, frames_from_iq_u8, window_count
         scale = DEFAULT_SCALE if scale is None else float(scale)
         as_numpy = not isinstance(iq, torch.Tensor)
+        if as_numpy and self.topology.kind != "cnnpy":      # host bytes: the library's streaming driver (mdc_predict_host_iq_u8)
+            b = np.ascontiguousarray(np.asarray(iq, dtype=np.uint8)).reshape(-1)
+            n, Cn = window_count(b.size, hop), self.topology.classes
+            probs, labels = np.empty((n, Cn), np.float32), np.empty((n,), np.int32)
+            _cabi.check(_cabi.lib().mdc_predict_host_iq_u8(self._engine(), b.ctypes.data, n, int(hop), scale, probs.ctypes.data,
+                                                           labels.ctypes.data, self._host_chunk(batch_size)))
+            return probs, labels
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(iq, dtype=np.uint8))) if as_numpy else iq
         if t.dtype != torch.uint8:
             raise TypeError(f"iq must be uint8, got {t.dtype}")

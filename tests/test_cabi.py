@@ -54,6 +54,8 @@ def test_new_entry_points_validate_their_arguments_without_gpu():
     assert L.mdc_forward_q612(None, None, 0, 1, None, None, None) == -22
     assert L.mdc_set_fp8_input_absmax(None, 1.0) == -22
     assert L.mdc_profile_read(None, 0, None, None) == -22 and L.mdc_profile_reset(None) == -22 and L.mdc_set_profiling(None, 1) == -22
+    assert L.mdc_predict_host(None, None, 4, None, None, 0) == -22 and b"null model" in L.mdc_last_error()
+    assert L.mdc_predict_host_iq_u8(None, None, 4, 128, 1.0, None, None, 0) == -22 and b"null model" in L.mdc_last_error()
     L.mdc_destroy(None)                                                                                   # a no-op, not a crash
 
 
