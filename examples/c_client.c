@@ -7,6 +7,8 @@
  * lanes > 1: the one-process multi-GPU form of BASELINE.json configs[3] ("per-GPU HIP streams") -- one model handle per
  * visible device, lanes streams dealt round-robin over the devices, the batch cut into contiguous shards, EVERY forward
  * enqueued from this one host thread before the first synchronisation, each stream synchronised once.
+ * lanes = 0: no device buffer in the caller at all -- the host arrays go through mdc_predict_host (the library's
+ * pinned-ring driver: copies, kernels and result copies overlapped on its own streams), as cnn.py:198 hands numpy arrays.
  *
  * weights.bin: float32 conv kernel (2F, HWIO), conv bias (F), dense kernel (258F x 3), dense bias (3);
  * frames.bin:  n x 2 x 128 float32;   out.bin: n x 3 float32 probabilities, then n int32 labels.
@@ -43,7 +45,9 @@ int main(int argc, char** argv) {
     const long n = atol(argv[3]);
     const int F = argc > 5 ? atoi(argv[5]) : 3;
     int lanes = argc > 6 ? atoi(argv[6]) : 1;
-    if (lanes < 1 || lanes > MAX_LANES) { fprintf(stderr, "lanes must be 1..%d\n", MAX_LANES); return 2; }
+    if (lanes < 0 || lanes > MAX_LANES) { fprintf(stderr, "lanes must be 0..%d\n", MAX_LANES); return 2; }
+    const int host_mode = lanes == 0;
+    if (host_mode) lanes = 1;
     const size_t nk0 = 2 * (size_t)F, nb0 = (size_t)F, nk1 = 258 * (size_t)F * 3, nb1 = 3;
     float* w = (float*)read_file(argv[1], (nk0 + nb0 + nk1 + nb1) * sizeof(float));
     float* x = (float*)read_file(argv[2], (size_t)n * 256 * sizeof(float));
@@ -75,7 +79,11 @@ int main(int argc, char** argv) {
     int32_t* l_dev[MAX_LANES];
     hipStream_t s[MAX_LANES];
     long lo[MAX_LANES + 1];
-    for (int i = 0; i <= lanes; ++i) lo[i] = (long)(((long long)i * n) / lanes);      /* contiguous, exhaustive shards */
+    if (host_mode) {      /* test_Y_hat = model.predict(X_test): host arrays in, host arrays out, chunks of 4,096 frames */
+        MDC_CHECK(mdc_predict_host(model[0], x, n, p, l, 4096));
+        lanes = 0;
+    }
+    for (int i = 0; i <= lanes; ++i) lo[i] = lanes ? (long)(((long long)i * n) / lanes) : 0;      /* contiguous, exhaustive shards */
     /* enqueue everything: uploads, forwards, downloads -- no synchronisation in this loop */
     for (int i = 0; i < lanes; ++i) {
         const int d = i % ndev;
@@ -104,6 +112,7 @@ int main(int argc, char** argv) {
         HIP_CHECK(hipStreamDestroy(s[i]));
     }
     free(w); free(x); free(p); free(l);
-    printf("c_client: %ld frames classified on %d device(s), %d stream(s)\n", n, ndev, lanes);
+    if (host_mode) printf("c_client: %ld frames classified from host buffers (mdc_predict_host)\n", n);
+    else printf("c_client: %ld frames classified on %d device(s), %d stream(s)\n", n, ndev, lanes);
     return 0;
 }

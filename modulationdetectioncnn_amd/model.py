@@ -291,18 +291,26 @@ class VTCNN2:
         return max(int(batch_size), HOST_MIN_CHUNK) if batch_size else 0
 
     def predict_host(self, X: np.ndarray, batch_size: Optional[int] = None, want_probs: bool = True,
-                     want_labels: bool = True) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+                     want_labels: bool = True, out=None) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
         """numpy frames in, numpy (probs, labels) out through the library's own host-buffer driver (mdc_predict_host:
-        pinned ring, copy / compute / result streams overlapped).  Bit-identical to the device path."""
+        pinned ring, copy / compute / result streams overlapped).  Bit-identical to the device path.  out = (probs,
+        labels): write into the caller's C-contiguous float32 (n,C) / int32 (n,) arrays (slices of a larger batch's)."""
         a = np.ascontiguousarray(np.asarray(X), dtype=np.float32)
         if a.ndim != 3 or a.shape[1:] != (2, 128):
             raise ValueError(f"expected input of shape (n,2,128); got {a.shape}")
         n, Cn = a.shape[0], self.topology.classes
-        probs = np.empty((n, Cn), np.float32) if want_probs else None
-        labels = np.empty((n,), np.int32) if want_labels else None
+        if out is not None:
+            probs, labels = out
+            for arr, shape, dt in ((probs, (n, Cn), np.float32), (labels, (n,), np.int32)):
+                if arr is not None and not (isinstance(arr, np.ndarray) and arr.shape == shape and arr.dtype == dt and arr.flags.c_contiguous
+                                            and arr.flags.writeable):
+                    raise ValueError(f"out arrays must be writeable C-contiguous {np.dtype(dt).name} of shape {shape}")
+        else:
+            probs = np.empty((n, Cn), np.float32) if want_probs else None
+            labels = np.empty((n,), np.int32) if want_labels else None
         _cabi.check(_cabi.lib().mdc_predict_host(self._engine(), a.ctypes.data, n,
-                                                 probs.ctypes.data if want_probs else None,
-                                                 labels.ctypes.data if want_labels else None, self._host_chunk(batch_size)))
+                                                 probs.ctypes.data if probs is not None else None,
+                                                 labels.ctypes.data if labels is not None else None, self._host_chunk(batch_size)))
         return probs, labels
 
     def _run(self, X, batch_size, tap):

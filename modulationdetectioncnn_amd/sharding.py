@@ -185,6 +185,31 @@ class MultiStreamPredictor:
         return np.concatenate(p), np.concatenate(l)
 
 
+    def predict_host(self, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Host batch in, host results out with every GPU's streaming driver (mdc_predict_host: pinned ring, copy /
+        compute / result streams) running at once: one host thread per model handle -- the C call releases the GIL
+        -- each feeding its device its contiguous shard and writing straight into its slice of the result arrays.
+        Per GPU the call runs at max(PCIe, kernel); nothing crosses between devices."""
+        from concurrent.futures import ThreadPoolExecutor
+        X = np.asarray(X)
+        models = []
+        for lane in self.lanes:
+            if not any(lane.model is m for m in models):
+                models.append(lane.model)
+        n = len(X)
+        probs = np.empty((n, self.classes), np.float32)
+        labels = np.empty((n,), np.int32)
+        jobs = [(m, lo, hi) for m, (lo, hi) in zip(models, shard_bounds(n, len(models))) if hi > lo]
+
+        def run(job):
+            m, lo, hi = job
+            m.predict_host(X[lo:hi], out=(probs[lo:hi], labels[lo:hi]))
+        if jobs:
+            with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+                list(ex.map(run, jobs))      # list(): re-raises a worker's exception here
+        return probs, labels
+
+
 def confusion_counts(labels_true: np.ndarray, labels_pred: np.ndarray, classes: int, reduce: bool = True) -> np.ndarray:
     """cnn.py:199-216 `conf[j,k] += 1` as a C x C histogram; with reduce=True the per-rank histograms are
     summed over ranks (C*C integers: the only cross-GPU reduction the evaluation path ever needs)."""

@@ -34,10 +34,11 @@ def test_c_client_compiles_and_links_without_cxx_or_torch(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,lanes", [(0, 1), (1, 1), (1000, 1), (1000, 3), (2, 3), (70001, 4)])
+@pytest.mark.parametrize("n,lanes", [(0, 1), (1, 1), (1000, 1), (1000, 3), (2, 3), (70001, 4), (0, 0), (1, 0), (70001, 0)])
 def test_c_client_reproduces_the_oracle(tmp_path, n, lanes):
     """lanes > 1: the one-process, per-GPU-stream form (BASELINE configs[3]) from plain C -- one handle per device, every
-    shard enqueued before the first synchronisation, one hipStreamSynchronize per stream."""
+    shard enqueued before the first synchronisation, one hipStreamSynchronize per stream.  lanes = 0: host buffers through
+    mdc_predict_host (18 chunks of 4,096 frames through the three slots for n = 70,001)."""
     from modulationdetectioncnn_amd import synthetic_frames
     from oracle import oracle_np as O
     import modulationdetectioncnn_amd.build as b
@@ -52,7 +53,7 @@ def test_c_client_reproduces_the_oracle(tmp_path, n, lanes):
     r = subprocess.run([str(exe), str(tmp_path / "w.bin"), str(tmp_path / "x.bin"), str(n), str(tmp_path / "out.bin"), "3", str(lanes)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert f"{lanes} stream(s)" in r.stdout
+    assert (f"{lanes} stream(s)" if lanes else "mdc_predict_host") in r.stdout
     raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint8)
     probs = raw[: n * 12].view(np.float32).reshape(n, 3)
     labels = raw[n * 12:].view(np.int32)

@@ -122,3 +122,22 @@ def test_host_path_errors():
     assert L.mdc_predict_host_iq_u8(cn._engine(), out.ctypes.data, 1, 128, 1.0, None, None, 0) == -95
     x = synthetic_frames(100, seed=1)
     np.testing.assert_array_equal(cn.predict(x), cn.predict(torch.from_numpy(x).cuda()).cpu().numpy())      # T4 through the driver too
+
+
+def test_out_arrays_and_the_multi_gpu_host_driver_on_one_gpu():
+    """results straight into slices of the caller's arrays; MultiStreamPredictor.predict_host with G = 1 device"""
+    from modulationdetectioncnn_amd.sharding import MultiStreamPredictor
+    m = _t1()
+    x = synthetic_frames(20000, seed=9)
+    want_p, want_l = _device_result(m, x)
+    P, Lb = np.zeros((20000, 3), np.float32), np.zeros((20000,), np.int32)
+    m.predict_host(x[5000:12000], out=(P[5000:12000], Lb[5000:12000]))
+    np.testing.assert_array_equal(P[5000:12000], want_p[5000:12000])
+    np.testing.assert_array_equal(Lb[5000:12000], want_l[5000:12000])
+    assert not P[:5000].any() and not P[12000:].any()
+    with pytest.raises(ValueError):
+        m.predict_host(x[:10], out=(P[:10, :2], Lb[:10]))          # not contiguous / wrong shape
+    msp = MultiStreamPredictor.for_models([m], streams_per_device=2)
+    p, l = msp.predict_host(x)
+    np.testing.assert_array_equal(p, want_p)
+    np.testing.assert_array_equal(l, want_l)

@@ -141,6 +141,45 @@ def test_multistream_driver_slices_enqueues_then_syncs_once(lanes, n):
         msp.forward_shards([X] * (lanes + 1))
 
 
+class _FakeHostModel:
+    """Stands for one GPU's VTCNN2 in the host-buffer driver: records its calls and the thread they ran on."""
+
+    def __init__(self, log, name, weights, barrier):
+        self.log, self.name, self.w, self.barrier = log, name, weights, barrier
+
+    def predict_host(self, X, out=None):
+        import threading
+        from oracle import oracle_np as O
+        self.barrier.wait(timeout=30)        # every model's call must be in flight at once: one thread per model
+        r = O.forward_deployed(np.asarray(X), *self.w, dtype=np.float32)
+        out[0][...] = r["probs"]
+        out[1][...] = r["labels"]
+        self.log.append((self.name, len(X), threading.get_ident()))
+
+
+@pytest.mark.parametrize("gpus,streams,n", [(1, 1, 10), (2, 1, 1001), (4, 2, 103), (3, 1, 2)])
+def test_multistream_host_driver_runs_every_device_at_once(gpus, streams, n):
+    """predict_host: one host thread per MODEL (not per lane), contiguous shards, results written in place."""
+    import threading
+    from types import SimpleNamespace
+    from modulationdetectioncnn_amd import synthetic_frames
+    from modulationdetectioncnn_amd.sharding import MultiStreamPredictor
+    from oracle import oracle_np as O
+    w = [a for p in load_deployed_npz("3convmodrecnets_CNN2_0.5") for a in p]
+    log = []
+    active = min(gpus, n)                      # shards of zero frames start no call
+    barrier = threading.Barrier(active)
+    models = [_FakeHostModel(log, g, w, barrier) for g in range(gpus)]
+    msp = MultiStreamPredictor([SimpleNamespace(model=m) for m in models for _ in range(streams)], 3)
+    X = synthetic_frames(n, seed=6)
+    p, l = msp.predict_host(X)
+    ref = O.forward_deployed(X, *w, dtype=np.float32)
+    np.testing.assert_array_equal(l, ref["labels"])
+    np.testing.assert_allclose(p, ref["probs"], atol=1e-6)      # (the numpy oracle's BLAS sums depend on the shard length)
+    assert sorted((name, cnt) for name, cnt, _ in log) == [(g, hi - lo) for g, (lo, hi) in enumerate(shard_bounds(n, gpus)) if hi > lo]
+    assert len({tid for _, _, tid in log}) == active
+
+
 def test_device_is_resolved_once_and_mismatch_is_an_error(monkeypatch):
     """with device=None the engine, the workspace and the input check must all use the device that was
     current when the model was built -- not whatever torch.cuda.current_device() says later."""
