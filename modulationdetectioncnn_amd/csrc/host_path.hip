@@ -142,14 +142,19 @@ int ctx_prepare(mdc_model* m, size_t in_bytes, int64_t frames) {
     if (!c) {
         c = new HostCtx();
         m->host_ctx = c;
-        MDC_HIP(hipStreamCreateWithFlags(&c->copy_s, hipStreamNonBlocking));
-        MDC_HIP(hipStreamCreateWithFlags(&c->comp_s, hipStreamNonBlocking));
-        MDC_HIP(hipStreamCreateWithFlags(&c->out_s, hipStreamNonBlocking));
-        for (Slot& s : c->slot) {
-            MDC_HIP(hipEventCreateWithFlags(&s.in_done, hipEventDisableTiming));
-            MDC_HIP(hipEventCreateWithFlags(&s.comp_done, hipEventDisableTiming));
-            MDC_HIP(hipEventCreateWithFlags(&s.out_done, hipEventDisableTiming));
-        }
+        auto create = [&]() -> int {
+            MDC_HIP(hipStreamCreateWithFlags(&c->copy_s, hipStreamNonBlocking));
+            MDC_HIP(hipStreamCreateWithFlags(&c->comp_s, hipStreamNonBlocking));
+            MDC_HIP(hipStreamCreateWithFlags(&c->out_s, hipStreamNonBlocking));
+            for (Slot& s : c->slot) {
+                MDC_HIP(hipEventCreateWithFlags(&s.in_done, hipEventDisableTiming));
+                MDC_HIP(hipEventCreateWithFlags(&s.comp_done, hipEventDisableTiming));
+                MDC_HIP(hipEventCreateWithFlags(&s.out_done, hipEventDisableTiming));
+            }
+            return MDC_OK;
+        };
+        const int rc = create();
+        if (rc != MDC_OK) { host_ctx_free(m); return rc; }      // never keep a half-made context for the next call
     }
     const int C = m->topo.classes;
     if (in_bytes > c->in_cap) {
@@ -199,6 +204,7 @@ int ctx_prepare(mdc_model* m, size_t in_bytes, int64_t frames) {
     return MDC_OK;
 }
 
+// (the first byte decides: a caller that pins its buffer pins all of it)
 bool is_pinned(const void* p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }

@@ -404,23 +404,24 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
         {
             ProfScope ps(m, 0, s);
             // per launch, like every other kernel here: the attribute is per DEVICE, and one process may drive several.
-            // Form by batch size (results identical): up to 64 frames one position per work-group (132 CUs per frame
-            // group), up to 384 three, up to 2,048 the batch blocking with one block per work-group, else the loop.
+            // Form by batch size (results identical): up to 128 frames one position per work-group (132 work-groups per
+            // 64-frame group), up to 2,048 three, up to 8,192 the batch blocking with one block per work-group, else the loop.
             const unsigned groups = (unsigned)((n + 63) / 64);
+            constexpr long t1 = 128, t3 = 2048, t11 = 8192;      // measured crossovers (conv us at n = 128 / 2,048 / 8,192: 90 / 668 / 2,140; the loop form 3,990 / 4,006 / 4,059)
 #define MDC_LAUNCH_CONV_F32(U, KP, YS) do { \
                 MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_f32_kernel<U, KP, YS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvF32Lds)); \
                 hipLaunchKernelGGL((vt_conv_f32_kernel<U, KP, YS>), dim3(groups, YS ? kW2 / KP : 1), dim3(256), kConvF32Lds, s, x, (long)n, \
                                    static_cast<const float*>(m->d_pack[0]), static_cast<const float*>(m->d_pack[1]), \
                                    static_cast<const float*>(m->d_pack[2]), static_cast<float*>(feat), hop2 > 0 ? hop2 : 256L, scale); } while (0)
             if (hop2 > 0) {
-                if (n <= 64) MDC_LAUNCH_CONV_F32(true, 1, true);
-                else if (n <= 384) MDC_LAUNCH_CONV_F32(true, 3, true);
-                else if (n <= 2048) MDC_LAUNCH_CONV_F32(true, 11, true);
+                if (n <= t1) MDC_LAUNCH_CONV_F32(true, 1, true);
+                else if (n <= t3) MDC_LAUNCH_CONV_F32(true, 3, true);
+                else if (n <= t11) MDC_LAUNCH_CONV_F32(true, 11, true);
                 else MDC_LAUNCH_CONV_F32(true, 11, false);
             } else {
-                if (n <= 64) MDC_LAUNCH_CONV_F32(false, 1, true);
-                else if (n <= 384) MDC_LAUNCH_CONV_F32(false, 3, true);
-                else if (n <= 2048) MDC_LAUNCH_CONV_F32(false, 11, true);
+                if (n <= t1) MDC_LAUNCH_CONV_F32(false, 1, true);
+                else if (n <= t3) MDC_LAUNCH_CONV_F32(false, 3, true);
+                else if (n <= t11) MDC_LAUNCH_CONV_F32(false, 11, true);
                 else MDC_LAUNCH_CONV_F32(false, 11, false);
             }
 #undef MDC_LAUNCH_CONV_F32
@@ -428,7 +429,7 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
         }
         {
             ProfScope ps(m, 1, s);
-            if (n <= 64)
+            if (n <= 2048)      // per-wave 16 x 16 tiles: 108 us at n = 256, 617 at 2,048; the 128 x 128 tiles take 1,140 us whatever the batch
                 hipLaunchKernelGGL(vt_dense1_f32_small_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s,
                                    static_cast<const float*>(feat), (long)n, static_cast<const float*>(m->d_pack[3]),
                                    static_cast<const float*>(m->d_pack[4]), hid);

@@ -180,10 +180,10 @@ def test_small_batch_forms_are_bit_identical_to_the_batch_kernels(dtype):
     not depend on how many frames it arrives with.  (The reference classifies one window per start pulse,
     cnn_test_latest1.sv:144-209.)"""
     m, _ = _model(11, dtype)
-    x = synthetic_frames(5000, seed=31, device="cuda")
-    big_p, big_l, _ = m.forward_device(x, batch_size=5000)            # batch kernels (n > 2,048)
-    big_h = m.predict(x, tap="hidden", batch_size=5000)
-    for n in (1, 2, 15, 16, 17, 33, 64, 65, 300, 384, 385, 1009, 1024, 1025, 2048, 2049):      # every launch form and its boundaries
+    x = synthetic_frames(9000, seed=31, device="cuda")
+    big_p, big_l, _ = m.forward_device(x, batch_size=9000)            # batch kernels (n > 8,192)
+    big_h = m.predict(x, tap="hidden", batch_size=9000)
+    for n in (1, 2, 15, 16, 17, 33, 64, 65, 128, 129, 300, 1009, 1024, 1025, 2048, 2049, 4097, 8192, 8193):      # every launch form and its boundaries
         xs = x[:n].contiguous()
         p, l, _ = m.forward_device(xs)
         assert torch.equal(p, big_p[:n]) and torch.equal(l, big_l[:n]), (dtype, n)
