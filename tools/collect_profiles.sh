@@ -24,7 +24,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES $P -d $R/gpurun_out/pmc_lds_vt -- $B > $R/gpurun_out/pmc_lds_vt.log 2>&1
 echo "vtcnn2 counters done"
 fi
-D="python3 $R/tools/prof_deployed.py f32 bf16 f16 u8"
+D="python3 $R/tools/prof_deployed.py f32 bf16 f16 fp8 u8"
 rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_dep -- $D > $R/gpurun_out/prof_${TAG}_dep.log 2>&1
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_dep -- $D > $R/gpurun_out/pmc_fetch_dep.log 2>&1
 rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_dep -- $D > $R/gpurun_out/pmc_write_dep.log 2>&1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 driver: a few forwards of the deployed F=3 / F=10 nets on 2^20 frames.
-    prof_deployed.py [f32] [bf16] [f16] [u8]     (default: f32 bf16 f16; u8 = the same dtypes on raw uint8 I/Q)
+    prof_deployed.py [f32] [bf16] [f16] [fp8] [u8]     (default: f32 bf16 f16; u8 = the same dtypes on raw uint8 I/Q)
 MDC_DEP_F32_MFMA=1 in the environment selects the f32 variant with the dense layer on the f32 matrix pipe."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,7 @@ n = 1 << 20
 x = synthetic_frames(n, seed=2016, device="cuda:0")
 iq = torch.randint(0, 256, (n * 256,), dtype=torch.uint8, device="cuda:0") if "u8" in args else None
 for f in ("3convmodrecnets_CNN2_0.5.npz", "convmodrecnets_CNN2_0.5.npz"):
-    for dt in ("f32", "bf16", "f16"):
+    for dt in ("f32", "bf16", "f16", "fp8"):
         if dt not in args:
             continue
         m = VTCNN2.from_npz(os.path.join(g, f), device=0, dtype=dt)

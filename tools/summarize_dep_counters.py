@@ -13,7 +13,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out = {}
 for d in sorted(glob.glob(os.path.join(G, f"pmc_{rnd}_dep*_[AB]"))):
     form = "f32 MFMA-dense variant" if "depmfma" in d else "default"
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:      # newest run only
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]

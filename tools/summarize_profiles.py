@@ -27,7 +27,7 @@ def counters(d, kern):
     if not fs:
         return {}
     out = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):      # gpurun merges new files next to old ones: newest run
         if kern in r["Kernel_Name"]:
             out[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in out.items()}
@@ -36,7 +36,7 @@ def counters(d, kern):
 os.makedirs(P, exist_ok=True)
 for d in sorted(glob.glob(os.path.join(G, "prof_*"))):
     tag = os.path.basename(d)[5:]
-    for f in glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:      # newest run only
         shutil.copy(f, os.path.join(P, (tag if tag.startswith(rnd) else f"{rnd}_{tag}") + "_kernel_stats.csv"))
 
 spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in that run)
@@ -45,17 +45,20 @@ spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in th
     ("mdc_vt_head", "vt", "vt_head_kernel", 65536),
     ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3, 0, 0, false, false>", 1 << 20),
     ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10, 0, 0, false, false>", 1 << 20),
-    ("mdc_deployed_fwd/F3/bf16", "dep", "deployed_bf16_kernel<3, false, false>", 1 << 20),
-    ("mdc_deployed_fwd/F10/bf16", "dep", "deployed_bf16_kernel<10, false, false>", 1 << 20),
-    ("mdc_deployed_fwd/F3/f16", "dep", "deployed_bf16_kernel<3, true, false>", 1 << 20),
-    ("mdc_deployed_fwd/F10/f16", "dep", "deployed_bf16_kernel<10, true, false>", 1 << 20),
+    # deployed_bf16_kernel<F, MODE, U8>: MODE 0 bf16, 1 f16, 2 fp8
+    ("mdc_deployed_fwd/F3/bf16", "dep", "deployed_bf16_kernel<3, 0, false>", 1 << 20),
+    ("mdc_deployed_fwd/F10/bf16", "dep", "deployed_bf16_kernel<10, 0, false>", 1 << 20),
+    ("mdc_deployed_fwd/F3/f16", "dep", "deployed_bf16_kernel<3, 1, false>", 1 << 20),
+    ("mdc_deployed_fwd/F10/f16", "dep", "deployed_bf16_kernel<10, 1, false>", 1 << 20),
+    ("mdc_deployed_fwd/F3/fp8", "dep", "deployed_bf16_kernel<3, 2, false>", 1 << 20),
+    ("mdc_deployed_fwd/F10/fp8", "dep", "deployed_bf16_kernel<10, 2, false>", 1 << 20),
     # raw uint8 I/Q input (256 B/frame): the U8 = true forms of the same kernels
     ("mdc_deployed_fwd/F3/u8", "dep", "deployed_fwd_kernel<3, 0, 0, false, true>", 1 << 20),
     ("mdc_deployed_fwd/F10/u8", "dep", "deployed_fwd_kernel<10, 0, 0, false, true>", 1 << 20),
-    ("mdc_deployed_fwd/F3/bf16/u8", "dep", "deployed_bf16_kernel<3, false, true>", 1 << 20),
-    ("mdc_deployed_fwd/F10/bf16/u8", "dep", "deployed_bf16_kernel<10, false, true>", 1 << 20),
-    ("mdc_deployed_fwd/F3/f16/u8", "dep", "deployed_bf16_kernel<3, true, true>", 1 << 20),
-    ("mdc_deployed_fwd/F10/f16/u8", "dep", "deployed_bf16_kernel<10, true, true>", 1 << 20),
+    ("mdc_deployed_fwd/F3/bf16/u8", "dep", "deployed_bf16_kernel<3, 0, true>", 1 << 20),
+    ("mdc_deployed_fwd/F10/bf16/u8", "dep", "deployed_bf16_kernel<10, 0, true>", 1 << 20),
+    ("mdc_deployed_fwd/F3/f16/u8", "dep", "deployed_bf16_kernel<3, 1, true>", 1 << 20),
+    ("mdc_deployed_fwd/F10/f16/u8", "dep", "deployed_bf16_kernel<10, 1, true>", 1 << 20),
 ]
 out = {"note": "bytes per launch; FETCH_SIZE doubled (gfx950 wide-read correction: calibrated for 16 B/lane streaming reads; the /u8 "
                "kernels read 8 B per lane or 16 B per LDS-DMA lane, so their read side is the guide's 'uncalibrated width' case -- the "
