@@ -346,6 +346,92 @@ __global__ __launch_bounds__(64) void vt_dense1_bf16_small_kernel(const unsigned
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The same tile for the smallest batches (<= 256 frames: at most one tile per CU), fed through LDS: the per-wave kernel
+// above is bound by load latency (two register sets of 20 fragment loads = 40 KB in flight per tile: 88 ns per MFMA of
+// a 330-MFMA dependent chain, 29 us for one window).  Here FOUR waves serve one tile: wave w moves fragment w of every
+// K-tile (A k 0..31, A k 32..63, B k 0..31, B k 32..63; 1 KiB each) by LDS-DMA into a ring of kRing K-tiles, kRing - 1
+// tiles ahead -- 4 x 23 KiB in flight, no registers spent on it -- and all four run the identical MFMA chain out of LDS
+// (reads of tile t+1 issued before the two MFMAs of tile t).  The fragments land in LDS in lane order and are read
+// back in lane order, so they are the per-wave kernel's fragments and the chain is its chain: bit-identical.  Wave 0
+// stores.  Ordering: a wave's counted vmcnt retires its own fragment of tile t+1, the barrier then covers the other
+// three; a slot is refilled two barriers after its last read.  kGrp K-tiles share one wait + barrier.
+// ------------------------------------------------------------------------------------
+constexpr int kRing = 24;                  // K-tiles in the ring
+constexpr int kGrp = 4;                    // K-tiles per step (one counted wait + one barrier per step)
+constexpr size_t kCoopLds = (size_t)kRing * 4096;
+
+__global__ __launch_bounds__(256) void vt_dense1_bf16_coop_kernel(const unsigned short* __restrict__ feat, long n,
+                                                                  const unsigned short* __restrict__ w1t,   // [165 k-tiles][256][64] bf16
+                                                                  const float* __restrict__ c1, float* __restrict__ hid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * 16;
+    const int col0 = blockIdx.y * 16;
+    long ar = row0 + fr;
+    if (ar >= n) ar = n - 1;                                  // rows past the end are computed, not stored
+    // this wave's fragment: A (wv = 0, 1) or B (wv = 2, 3), k half wv & 1; per-lane source as in the per-wave kernel
+    const unsigned short* src = (wv < 2 ? feat + ar * (long)kFeat : w1t + (long)(col0 + fr) * kBK) + fg * 8 + (wv & 1) * 32;
+    const long kstep = wv < 2 ? (long)kBK : (long)kBN * kBK;
+    static_assert(kRing % kGrp == 0, "groups do not straddle the ring's end");
+    constexpr int kAhead = kRing / kGrp - 1;                 // groups in flight
+    constexpr int kGroups = kNT / kGrp, kTail = kNT - kGroups * kGrp;      // 41 full groups + 1 tile
+    auto issue = [&](int g) {      // group g (tiles clamped: the tail keeps the count of outstanding copies uniform) -> its ring slots
+#pragma unroll
+        for (int j = 0; j < kGrp; ++j) {
+            const int t = g * kGrp + j, tc = t < kNT ? t : kNT - 1;
+            glds16_async(src + tc * kstep, smem + (size_t)(t % kRing) * 4096 + wv * 1024);
+        }
+    };
+    auto read = [&](bf16x8 (&f)[kGrp][4], int g) {
+        const unsigned char* base = smem + (size_t)((g * kGrp) % kRing) * 4096 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < kGrp; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[j][q] = *reinterpret_cast<const bf16x8*>(base + j * 4096 + q * 1024);
+    };
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const bf16x8 (&f)[kGrp][4], int tiles) {
+#pragma unroll
+        for (int j = 0; j < kGrp; ++j)
+            if (j < tiles) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j][0], f[j][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j][1], f[j][3], acc, 0, 0, 0);
+            }
+    };
+    bf16x8 f0[kGrp][4], f1[kGrp][4];
+    for (int g = 0; g < kAhead; ++g) issue(g);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kAhead - 1) * kGrp) : "memory");      // own fragments of group 0, then everybody's
+    read(f0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto step = [&](bf16x8 (&cur)[kGrp][4], bf16x8 (&nxt)[kGrp][4], int g) {
+        issue(g + kAhead);                                                       // outstanding now: groups g+1 .. g+kAhead
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kAhead - 1) * kGrp) : "memory");   // own fragments of group g+1 landed, then everybody else's
+        read(nxt, g + 1);
+        mma(cur, kGrp);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    static_assert(kGroups % 2 == 1 && kTail >= 0 && kTail < kGrp, "pairs of steps, a last full group, then the tail tiles");
+    for (int g = 0; g < kGroups - 1; g += 2) {
+        step(f0, f1, g);
+        step(f1, f0, g + 1);
+    }
+    step(f0, f1, kGroups - 1);         // last full group; f1 <- the tail group (tiles past the end are clamped copies, not used)
+    mma(f1, kTail);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the clamped tail copies: nothing in flight at exit
+    if (wv != 0) return;
+    const int col = col0 + fr;
+    const float bias = c1[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long row = row0 + fg * 4 + r;
+        if (row < n) hid[row * kHid + col] = fmaxf(acc[r] + bias, 0.f);
+    }
+}
+
+constexpr long kCoopBatch = 256;       // frames up to which one tile per CU is the whole layer: the four-wave form
+
 // frames up to which the per-wave kernel is used: 16 x n/16 waves of 16 x 16 outputs beat the 256-row tiles (one
 // work-group per 256 frames, 178 us whatever the batch) up to about 2,048 frames (tools/latency.py: 260 vs 296 us there)
 constexpr long kSmallBatch = 2048;
@@ -353,6 +439,14 @@ constexpr long kSmallBatch = 2048;
 }  // namespace
 
 int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s) {
+    if (n <= kCoopBatch) {
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
+        hipLaunchKernelGGL(vt_dense1_bf16_coop_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(256), kCoopLds, s,
+                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
+                           static_cast<const float*>(m->d_pack[4]), hid);
+        MDC_HIP(hipGetLastError());
+        return MDC_OK;
+    }
     if (n <= kSmallBatch) {
         hipLaunchKernelGGL(vt_dense1_bf16_small_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s,
                            static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
