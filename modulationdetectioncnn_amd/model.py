@@ -61,6 +61,7 @@ class VTCNN2:
         self._weights: Optional[Weights] = None
         self._handle: Optional[C.c_void_p] = None
         self._ws = {}
+        self._ws_need = {}      # frames per launch -> mdc_workspace_bytes (a property of the finalized model)
         self.default_chunk = 1 << 16 if topology.kind == "vtcnn2" else 1 << 22
 
     # ------------------------------------------------------------------ construction
@@ -214,6 +215,7 @@ class VTCNN2:
             _cabi.lib().mdc_destroy(self._handle)
             self._handle = None
         self._ws = {}
+        self._ws_need = {}
 
     def __del__(self):
         try:
@@ -221,16 +223,17 @@ class VTCNN2:
         except Exception:
             pass
 
-    def _workspace(self, n: int):
-        L = _cabi.lib()
-        need = int(L.mdc_workspace_bytes(self._engine(), n))
+    def _workspace(self, n: int, stream_key: Optional[int] = None):
+        need = self._ws_need.get(n)
+        if need is None:
+            need = self._ws_need[n] = int(_cabi.lib().mdc_workspace_bytes(self._engine(), n))
         if need == 0:
             return None, 0
         torch = _torch()
         # one scratch buffer PER STREAM: forwards enqueued on different streams run concurrently and must not share
         # it (the C ABI leaves the workspace to the caller for exactly this reason); allocated under the stream
         # that uses it, so torch's caching allocator orders any reuse after the launches already queued there
-        key = torch.cuda.current_stream(torch.device("cuda", self.device_index)).cuda_stream
+        key = stream_key if stream_key is not None else torch.cuda.current_stream(torch.device("cuda", self.device_index)).cuda_stream
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=f"cuda:{self.device_index}")
@@ -273,8 +276,8 @@ class VTCNN2:
             return probs, labels, tap_out
         chunk = int(batch_size) if batch_size else self.default_chunk
         chunk = max(1, min(chunk, n))
-        ws, ws_bytes = self._workspace(chunk)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = torch.cuda.current_stream(dev).cuda_stream      # (2 us: looked up once per call)
+        ws, ws_bytes = self._workspace(chunk, stream)
         tap_row = int(np.prod(self.tap_shape(tap))) if tap is not None else 0
         for s in range(0, n, chunk):
             m = min(chunk, n - s)
@@ -498,8 +501,8 @@ class VTCNN2:
             L, h = _cabi.lib(), self._engine()
             chunk = max(1, min(int(batch_size) if batch_size else self.default_chunk, n))
             with torch.cuda.device(t.device):
-                ws, ws_bytes = self._workspace(chunk)
                 stream = torch.cuda.current_stream(t.device).cuda_stream
+                ws, ws_bytes = self._workspace(chunk, stream)
                 for s0 in range(0, n, chunk):
                     m = min(chunk, n - s0)
                     _cabi.check(L.mdc_forward_iq_u8(h, t.data_ptr() + 2 * hop * s0, m, hop, scale,
