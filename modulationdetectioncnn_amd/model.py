@@ -62,7 +62,11 @@ class VTCNN2:
         self._handle: Optional[C.c_void_p] = None
         self._ws = {}
         self._ws_need = {}      # frames per launch -> mdc_workspace_bytes (a property of the finalized model)
-        self.default_chunk = 1 << 16 if topology.kind == "vtcnn2" else 1 << 22
+        # frames per mdc_forward call when the caller gives no batch_size.  VT-CNN2: the workspace holds a call's features
+        # (21 KB/frame in the 16-bit modes): 65,536 frames per call in f32, 2^20 in bf16 / fp8 -- one launch of each kernel for
+        # the headline batch (23 GB of workspace, of 288; +1.5 % over sixteen 65,536-frame launches: each conv launch
+        # reloads its 245 KB of weight fragments per work-group, each dense1 launch has a tail)
+        self.default_chunk = (1 << 20 if dtype in ("bf16", "fp8") else 1 << 16) if topology.kind == "vtcnn2" else 1 << 22
 
     # ------------------------------------------------------------------ construction
     @classmethod

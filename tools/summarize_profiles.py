@@ -40,9 +40,9 @@ for d in sorted(glob.glob(os.path.join(G, "prof_*"))):
         shutil.copy(f, os.path.join(P, (tag if tag.startswith(rnd) else f"{rnd}_{tag}") + "_kernel_stats.csv"))
 
 spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in that run)
-    ("mdc_vt_conv/bf16", "vt", "vt_conv_bf16", 65536),
-    ("mdc_vt_dense1/bf16", "vt", "vt_dense1_bf16", 65536),
-    ("mdc_vt_head", "vt", "vt_head_kernel", 65536),
+    ("mdc_vt_conv/bf16", "vt", "vt_conv_bf16", 1 << 20),      # bench.py's headline: one launch per 2^20-frame step
+    ("mdc_vt_dense1/bf16", "vt", "vt_dense1_bf16", 1 << 20),
+    ("mdc_vt_head", "vt", "vt_head_kernel", 1 << 20),
     ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3, 0, 0, false, false>", 1 << 20),
     ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10, 0, 0, false, false>", 1 << 20),
     # deployed_bf16_kernel<F, MODE, U8>: MODE 0 bf16, 1 f16, 2 fp8
