@@ -218,7 +218,11 @@ int run_pipeline(mdc_model* m, const char* src, int64_t n, int64_t chunk, float*
     HostCtx* c = static_cast<HostCtx*>(m->host_ctx);
     const int C = m->topo.classes;
     const bool direct = is_pinned(src);
-    CopyPool pool(direct ? 0 : std::max(0, std::min<int>(kCopyThreads, (int)std::thread::hardware_concurrency()) - 1));
+    // helper threads only where they pay: a few-frame call (one window of a live stream) must not spend 100 us starting them
+    size_t total_off = 0, total_bytes = 0;
+    in_range(0, n, &total_off, &total_bytes);
+    const bool helpers = !direct && total_bytes >= ((size_t)8 << 20);
+    CopyPool pool(helpers ? std::max(0, std::min<int>(kCopyThreads, (int)std::thread::hardware_concurrency()) - 1) : 0);
     auto retire = [&](Slot& s) -> int {
         if (!s.busy) return MDC_OK;
         MDC_HIP(hipEventSynchronize(s.out_done));
@@ -270,6 +274,14 @@ int run_pipeline(mdc_model* m, const char* src, int64_t n, int64_t chunk, float*
     return rc;
 }
 
+// Slot length when the caller names none: 65,536 frames for large batches; a mid-size batch is cut into about four chunks
+// (never below 8,192 frames: the VT-CNN2 kernels lose efficiency on smaller launches) so that its copies and kernels overlap too
+int64_t default_chunk(int64_t n) {
+    if (n >= 4 * kDefaultChunkFrames) return kDefaultChunkFrames;
+    const int64_t q = ((n + 3) / 4 + 255) & ~(int64_t)255;
+    return std::min<int64_t>(kDefaultChunkFrames, std::max<int64_t>(8192, q));
+}
+
 int check_common(const char* who, const mdc_model* m, const void* in, int64_t n, int64_t chunk) {
     if (!m) { set_error("%s: null model", who); return MDC_EINVAL; }
     if (!m->finalized) { set_error("%s: model not finalized", who); return MDC_ESTATE; }
@@ -287,7 +299,7 @@ int predict_host(mdc_model* m, const float* x_host, int64_t n, float* probs_host
     std::lock_guard<std::mutex> g(m->host_mu);
     DeviceScope dev(m->device);
     if (!dev.ok) { set_error("mdc_predict_host: cannot select device %d", m->device); return MDC_EIO; }
-    const int64_t chunk = std::min<int64_t>(chunk_frames > 0 ? chunk_frames : kDefaultChunkFrames, n);
+    const int64_t chunk = std::min<int64_t>(chunk_frames > 0 ? chunk_frames : default_chunk(n), n);
     if ((rc = ctx_prepare(m, (size_t)chunk * kFrameFloats * 4, chunk)) != MDC_OK) return rc;
     return run_pipeline(
         m, reinterpret_cast<const char*>(x_host), n, chunk, probs_host, labels_host,
@@ -310,7 +322,7 @@ int predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int64_t 
     std::lock_guard<std::mutex> g(m->host_mu);
     DeviceScope dev(m->device);
     if (!dev.ok) { set_error("mdc_predict_host_iq_u8: cannot select device %d", m->device); return MDC_EIO; }
-    int64_t chunk = std::min<int64_t>(chunk_frames > 0 ? chunk_frames : kDefaultChunkFrames, n);
+    int64_t chunk = std::min<int64_t>(chunk_frames > 0 ? chunk_frames : default_chunk(n), n);
     if (chunk_frames <= 0) {      // default: a slot's input stays within the f32 path's 64 MiB however large the hop
         const int64_t fit = ((kDefaultChunkFrames * kFrameFloats * 4) - 256) / (2 * hop) + 1;
         chunk = std::max<int64_t>(1, std::min(chunk, fit));
