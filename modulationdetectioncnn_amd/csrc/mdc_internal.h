@@ -69,6 +69,7 @@ struct mdc_model {
 
     // fp8 mode (vtcnn2): largest |sample| the caller expects (sets the activation scale) and the resulting
     // power-of-two scale of the features, 2^fp8_feat_scale_log2 (vtcnn2_fp8_conv.hip)
+    bool dep_pivot = false;      // deployed F = 10: the pivot-form table (d_pack[6]) exists (deployed.hip)
     float fp8_input_absmax = 0.02f;
     int fp8_feat_scale_log2 = 0;
 

@@ -407,3 +407,79 @@ def test_fp8_mode_of_the_deployed_nets(name):
     xl = synthetic_frames(512, seed=9, sigma=0.5)
     refl = O.forward_deployed(xl, *flat, dtype=np.float64)
     assert np.abs(mbig.predict(xl) - refl["probs"]).max() < 8e-2
+
+
+# ---- F = 10, f32: the pivot form of the conv (one fma + one med3 per output; deployed.hip) and the plain form behind it
+@pytest.mark.parametrize("n", [1, 63, 65, 70001])
+def test_pivot_and_plain_conv_forms_both_meet_the_oracle(monkeypatch, n):
+    """The bundled 10-filter net takes the pivot form (every K1 != 0); MDC_DEP_PIVOT=0 selects the plain two-fma form.
+    Both are held to the f64 oracle at the f32 bar, frames and raw bytes, and they agree with each other."""
+    name = "convmodrecnets_CNN2_0.5"
+    x = synthetic_frames(n, seed=77) * np.float32(2.5)
+    w = [a for p in load_deployed_npz(name) for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)
+    scale = max(1.0, float(np.abs(ref["dense"]).max()))
+    m = _model(name)
+    got = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("MDC_DEP_PIVOT", form)
+        d, p, l = m.predict(x, tap="dense"), m.predict(x), m.predict_classes(x)
+        np.testing.assert_allclose(d, ref["dense"], rtol=0, atol=2e-6 * scale)
+        np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
+        _check_labels(l, ref)
+        got[form] = (d, p, l)
+    np.testing.assert_allclose(got["1"][1], got["0"][1], rtol=0, atol=1e-6)
+    assert not np.array_equal(got["1"][0], got["0"][0]) or n == 1      # they ARE different arithmetic (n = 1 may coincide)
+
+
+def test_degenerate_conv_taps_fall_back_to_the_plain_form(monkeypatch):
+    """A filter whose second tap is zero (or whose tap ratio is huge) has no pivot: the library must run the plain form
+    -- the results are then bit-identical with and without MDC_DEP_PIVOT=0 -- and still meet the oracle."""
+    topo = Topology.deployed(10, 3)
+    (ck, cb), (dk, db) = synthetic_weights(topo, seed=5, bias_scale=0.05)
+    ck = np.array(ck, np.float32)
+    ck.reshape(2, 10)[1, 3] = 0.0            # K1[3] = 0
+    ck.reshape(2, 10)[1, 7] = 1e-30          # |K0/K1| ~ 1e29
+    x = synthetic_frames(5000, seed=8) * np.float32(3.0)
+    ref = O.forward_deployed(x, ck, cb, dk, db, dtype=np.float64)
+    outs = []
+    for form in ("1", "0"):
+        monkeypatch.setenv("MDC_DEP_PIVOT", form)
+        m = VTCNN2(topo)
+        m.set_weights([(ck, cb), (dk, db)])
+        p = m.predict(x)
+        np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
+        outs.append(p)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    # large conv biases: the folded constant sum(D*b) would have to cancel large inactive terms -> plain form as well
+    (ck2, cb2), (dk2, db2) = synthetic_weights(topo, seed=6, bias_scale=0.05)
+    cb2 = np.full(10, 5.0, np.float32)
+    ref2 = O.forward_deployed(x, ck2, cb2, dk2, db2, dtype=np.float64)
+    outs = []
+    for form in ("1", "0"):
+        monkeypatch.setenv("MDC_DEP_PIVOT", form)
+        m = VTCNN2(topo)
+        m.set_weights([(ck2, cb2), (dk2, db2)])
+        d = m.predict(x, tap="dense")
+        np.testing.assert_allclose(d, ref2["dense"], rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref2["dense"]).max())))
+        outs.append(d)
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_pivot_form_negative_and_positive_pivots_with_biases():
+    """both signs of K1, biases of both signs and a saturating input scale: the (lo, hi) clamp and the folded constants"""
+    topo = Topology.deployed(10, 3)
+    rng = np.random.default_rng(11)
+    ck = rng.normal(0, 1, (1, 2, 1, 10)).astype(np.float32)
+    ck.reshape(2, 10)[1] = np.array([-2, -1, -0.5, -0.25, -3, 2, 1, 0.5, 0.25, 3], np.float32)
+    cb = rng.normal(0, 0.05, 10).astype(np.float32)
+    dk = rng.normal(0, 0.05, (2580, 3)).astype(np.float32)      # sum|D||b| ~ 5: pivot form
+    db = np.array([0.3, -0.2, 0.1], np.float32)
+    m = VTCNN2(topo)
+    m.set_weights([(ck, cb), (dk, db)])
+    for s in (0.01, 1.0, 30.0):
+        x = synthetic_frames(4096, seed=3, sigma=1.0) * np.float32(s)
+        ref = O.forward_deployed(x, ck, cb, dk, db, dtype=np.float64)
+        scale = max(1.0, float(np.abs(ref["dense"]).max()))
+        np.testing.assert_allclose(m.predict(x, tap="dense"), ref["dense"], rtol=0, atol=4e-6 * scale)
+        _check_labels(m.predict_classes(x), ref)
