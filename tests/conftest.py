@@ -14,6 +14,12 @@ REFERENCE = "/root/reference"          # exists only in the build container, nev
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:      # property tests: the same examples on every run (a suite run must not depend on a seed), no wall-clock deadline
+        from hypothesis import settings
+        settings.register_profile("repo", derandomize=True, deadline=None, database=None)
+        settings.load_profile("repo")
+    except ImportError:
+        pass
 
 
 def _have_gpu():
