@@ -278,7 +278,7 @@ def run_q612(filters, device, steps=10, warmup=3, n=1 << 20):
     gbs = (1024 + 16) * n * steps / el / 1e9
     return {"workload": f"deployed{filters}-q612-n2^20", "value": n * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
             "dtype": "int18/int32 (Q6.12)", "roofline": {"bound": "int-valu", "kernel": "mdc_deployed_q612", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": measured_traffic(f"mdc_deployed_q612/F{filters}", n),
                                                         "from": "wall time incl. two small output allocations, one launch per step; HBM fraction reported, the bound is 64-bit integer VALU"}}
 
 

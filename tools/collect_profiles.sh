@@ -22,9 +22,17 @@ rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt -- $B > $R/gpurun_ou
 rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_vt -- $B > $R/gpurun_out/pmc_write_vt.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA $P -d $R/gpurun_out/pmc_mfma_vt -- $B > $R/gpurun_out/pmc_mfma_vt.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES $P -d $R/gpurun_out/pmc_lds_vt -- $B > $R/gpurun_out/pmc_lds_vt.log 2>&1
+# HBM traffic of the other two VT-CNN2 modes' kernels (fp8 conv2 at 2^20 frames, f32 at 65,536): bench.py's extra legs
+for W in "vtcnn2-c11-fp8-n2^20:fp8" "vtcnn2-c3-f32-n65536:f32"; do
+  WL=${W%%:*}; SFX=${W##*:}
+  BW="python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+  rm -rf $R/gpurun_out/pmc_fetch_vt$SFX $R/gpurun_out/pmc_write_vt$SFX
+  rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt$SFX -- $BW > $R/gpurun_out/pmc_fetch_vt$SFX.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_vt$SFX -- $BW > $R/gpurun_out/pmc_write_vt$SFX.log 2>&1
+done
 echo "vtcnn2 counters done"
 fi
-D="python3 $R/tools/prof_deployed.py f32 bf16 f16 fp8 u8"
+D="python3 $R/tools/prof_deployed.py f32 bf16 f16 fp8 u8 q612"
 rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_dep -- $D > $R/gpurun_out/prof_${TAG}_dep.log 2>&1
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_dep -- $D > $R/gpurun_out/pmc_fetch_dep.log 2>&1
 rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_dep -- $D > $R/gpurun_out/pmc_write_dep.log 2>&1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 driver: a few forwards of the deployed F=3 / F=10 nets on 2^20 frames.
-    prof_deployed.py [f32] [bf16] [f16] [fp8] [u8]     (default: f32 bf16 f16; u8 = the same dtypes on raw uint8 I/Q)
+    prof_deployed.py [f32] [bf16] [f16] [fp8] [u8] [q612]     (default: f32 bf16 f16; u8 = the same dtypes on raw uint8 I/Q; q612 = the integer forward)
 MDC_DEP_F32_MFMA=1 in the environment selects the f32 variant with the dense layer on the f32 matrix pipe."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,4 +21,6 @@ for f in ("3convmodrecnets_CNN2_0.5.npz", "convmodrecnets_CNN2_0.5.npz"):
             m.forward_device(x)
             if iq is not None:
                 m.predict_iq_u8(iq, 0.02 / 127.5)
+            if dt == "f32" and "q612" in args:
+                m.predict_q612(x, as_float=False)
 torch.cuda.synchronize()

@@ -43,8 +43,12 @@ spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in th
     ("mdc_vt_conv/bf16", "vt", "vt_conv_bf16", 1 << 20),      # bench.py's headline: one launch per 2^20-frame step
     ("mdc_vt_dense1/bf16", "vt", "vt_dense1_bf16", 1 << 20),
     ("mdc_vt_head", "vt", "vt_head_kernel", 1 << 20),
-    ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3, 0, 0, false, false>", 1 << 20),
-    ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10, 0, 0, false, false>", 1 << 20),
+    ("mdc_vt_conv/fp8", "vtfp8", "vt_conv_fp8_kernel", 1 << 20),
+    ("mdc_vt_dense1/fp8", "vtfp8", "vt_dense1_bf16", 1 << 20),
+    ("mdc_vt_conv/f32", "vtf32", "vt_conv_f32_kernel", 1 << 16),
+    ("mdc_vt_dense1/f32", "vtf32", "vt_dense1_f32_kernel", 1 << 16),
+    ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3, 0, 0, false, false, false>", 1 << 20),      # <F, TAP, ABL, TAIL, U8, PIV>
+    ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10, 0, 0, false, false, true>", 1 << 20),      # the pivot form (bundled net)
     # deployed_bf16_kernel<F, MODE, U8>: MODE 0 bf16, 1 f16, 2 fp8
     ("mdc_deployed_fwd/F3/bf16", "dep", "deployed_bf16_kernel<3, 0, false>", 1 << 20),
     ("mdc_deployed_fwd/F10/bf16", "dep", "deployed_bf16_kernel<10, 0, false>", 1 << 20),
@@ -52,9 +56,11 @@ spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in th
     ("mdc_deployed_fwd/F10/f16", "dep", "deployed_bf16_kernel<10, 1, false>", 1 << 20),
     ("mdc_deployed_fwd/F3/fp8", "dep", "deployed_bf16_kernel<3, 2, false>", 1 << 20),
     ("mdc_deployed_fwd/F10/fp8", "dep", "deployed_bf16_kernel<10, 2, false>", 1 << 20),
+    ("mdc_deployed_q612/F3", "dep", "deployed_q612_kernel<3>", 1 << 20),
+    ("mdc_deployed_q612/F10", "dep", "deployed_q612_kernel<10>", 1 << 20),
     # raw uint8 I/Q input (256 B/frame): the U8 = true forms of the same kernels
-    ("mdc_deployed_fwd/F3/u8", "dep", "deployed_fwd_kernel<3, 0, 0, false, true>", 1 << 20),
-    ("mdc_deployed_fwd/F10/u8", "dep", "deployed_fwd_kernel<10, 0, 0, false, true>", 1 << 20),
+    ("mdc_deployed_fwd/F3/u8", "dep", "deployed_fwd_kernel<3, 0, 0, false, true, false>", 1 << 20),
+    ("mdc_deployed_fwd/F10/u8", "dep", "deployed_fwd_kernel<10, 0, 0, false, true, true>", 1 << 20),
     ("mdc_deployed_fwd/F3/bf16/u8", "dep", "deployed_bf16_kernel<3, 0, true>", 1 << 20),
     ("mdc_deployed_fwd/F10/bf16/u8", "dep", "deployed_bf16_kernel<10, 0, true>", 1 << 20),
     ("mdc_deployed_fwd/F3/f16/u8", "dep", "deployed_bf16_kernel<3, 1, true>", 1 << 20),
