@@ -2,6 +2,7 @@
 is chunked, wherever a window starts in a capture and whichever entry point carries it, a frame's result is the same
 bits.  Ragged tails, single frames, odd hops (2-byte aligned windows) and chunk boundaries come up by themselves."""
 import functools
+import os
 
 import numpy as np
 import pytest
@@ -12,7 +13,6 @@ from modulationdetectioncnn_amd import VTCNN2, Topology, _cabi, frames_from_iq_u
 
 pytestmark = pytest.mark.gpu
 
-import os
 # reproducible examples by default (the round-end run must not depend on a seed); MDC_PROP_EXAMPLES=N draws N random ones
 _N = int(os.environ.get("MDC_PROP_EXAMPLES", "0"))
 _S = dict(max_examples=_N, derandomize=False, deadline=None) if _N else dict(max_examples=40, derandomize=True, deadline=None)
