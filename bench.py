@@ -13,6 +13,11 @@ BASELINE.json's metric is quoted on: canonical VT-CNN2 (11 classes), batch 2^20,
 with f32 accumulation (configs[2]).  Other BASELINE configs that fit one GPU are run as
 short `extra` legs (not the headline value):  --workload selects any of them as headline.
 
+N > 1: the headline line is the weak-scaling reading (2^20 frames PER GPU).  The metric's
+"batch=2^20 at 1/2/4/8 MI355X" also reads as a fixed 2^20-frame global batch, and configs[3]
+names 2^24 frames over 8 GPUs (2^21 per GPU): both are run by every rank as `extra` legs
+("scaling": "strong" / "weak", with global_batch and frames_per_gpu stated), same timing contract.
+
 roofline: the dominant kernel's algorithmic FLOPs (MFMA-bound nets) or bytes (HBM-bound
 nets) per launch / its mean launch duration, measured with HIP events recorded inside
 mdc_forward on the launch stream in a separate, untimed pass.
@@ -77,15 +82,18 @@ def make_model(name, device):
 
 
 def measured_traffic(key, frames_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json, made by
-    tools/summarize_profiles.py on the GPU box: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
-    corrections applied).  Scaled by frames per launch; None if no profile covers this kernel."""
+    """(HBM bytes per launch, where the number comes from).  NOT measured in this run: PMC counters need rocprofv3 around
+    the process, so the bytes per frame come from the newest COMMITTED rocprofv3 PMC passes (profiles/rNN_traffic.json,
+    made by tools/summarize_profiles.py on the GPU box: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections
+    applied) and are scaled by this run's frames per launch; (None, None) if no profile covers this kernel."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
+        return None, None
     k = json.load(open(files[-1])).get("kernels", {}).get(key)
-    return None if k is None else k["hbm_bytes_per_frame"] * frames_per_launch
+    if k is None:
+        return None, None
+    return k["hbm_bytes_per_frame"] * frames_per_launch, f"profiles/{os.path.basename(files[-1])} (committed rocprofv3 PMC pass, bytes per frame x frames per launch; not measured in this run)"
 
 
 def dominant_roofline(m, x, probs, labels, steps):
@@ -94,7 +102,7 @@ def dominant_roofline(m, x, probs, labels, steps):
     topo = m.topology
     m.set_profiling(True)
     for _ in range(steps):
-        m.forward_device(x, probs=probs, labels=labels)
+        m.forward_device(x, probs=probs, labels=labels, batch_size=getattr(m, "bench_chunk", None))
     torch.cuda.synchronize()
     prof = m.read_profile()
     m.set_profiling(False)
@@ -103,14 +111,17 @@ def dominant_roofline(m, x, probs, labels, steps):
     launches_per_step = max(1, cnt // steps)
     frames_per_launch = n / launches_per_step
     avg_ms = ms / cnt
+    # (a slot without launches: the VT-CNN2 head, which the 16-bit batch path runs inside dense1's epilogue)
     kernels = {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] // steps} for k, v in prof.items()}
     if topo.kind == "vtcnn2":
-        flops = {"mdc_vt_conv": topo.conv_flops_per_frame, "mdc_vt_dense1": 2 * 10560 * 256,
+        fused_head = prof.get("mdc_vt_head", (0.0, 0))[1] == 0
+        flops = {"mdc_vt_conv": topo.conv_flops_per_frame, "mdc_vt_dense1": 2 * 10560 * 256 + (2 * 256 * topo.classes if fused_head else 0),
                  "mdc_vt_head": 2 * 256 * topo.classes}[name] * frames_per_launch
         ach = flops / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[m.dtype]
+        traffic, tsrc = measured_traffic(f"{name}/{m.dtype}", frames_per_launch)
         rl = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-              "frac": ach / peak, "traffic": measured_traffic(f"{name}/{m.dtype}", frames_per_launch),
+              "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
               "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
     else:
         rl = deployed_roofline(topo, m.dtype, name, avg_ms, frames_per_launch, "frames")
@@ -123,14 +134,14 @@ def deployed_roofline(topo, dtype, name, avg_ms, frames_per_launch, source):
     by = (topo.io_bytes_per_frame if source == "frames" else 256 + 4 * topo.classes) * frames_per_launch
     gbs = by / (avg_ms * 1e-3) / 1e9
     key = (f"{name}/F{topo.filters}" + ("/" + dtype if dtype != "f32" else "") + ("/u8" if source == "u8" else "")) if topo.kind == "deployed" else name
-    traffic = measured_traffic(key, frames_per_launch)
+    traffic, tsrc = measured_traffic(key, frames_per_launch)
     if (topo.kind, topo.filters, dtype, source) in VALU_BOUND:
         tf = topo.flops_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e12
         return {"bound": "valu", "kernel": name, "achieved": tf, "peak": PEAK_VALU_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / PEAK_VALU_F32_TFLOPS, "traffic": traffic, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
-                "hbm_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
+                "frac": tf / PEAK_VALU_F32_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms,
+                "frames_per_launch": frames_per_launch, "hbm_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
     return {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-            "traffic": traffic, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
+            "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
 
 
 def usable_cpus():
@@ -211,19 +222,47 @@ def cpu_baseline(name, budget_s=20.0):
     return best
 
 
-def run_workload(name, device, steps, warmup, dist=None):
+def launch_chunk(kind, dtype, n):
+    """Frames per mdc_forward call.  The library's default for the VT-CNN2 family is 65,536 (1.45 GB of workspace per
+    stream); the bench has the HBM to spare and asks for ONE launch of each kernel per 2^20 frames in the 16-bit modes
+    (23 GB of workspace, +1.5 % over sixteen launches) -- stated in the JSON line's config."""
+    if kind == "vtcnn2" and dtype in ("bf16", "fp8"):
+        return min(n, 1 << 20)
+    return None
+
+
+def run_workload(name, device, steps, warmup, dist=None, frames=None):
+    """frames: per-GPU batch of THIS rank when it differs from the workload's own (the strong-scaling leg)."""
     import torch
     from modulationdetectioncnn_amd import synthetic_frames
     m, n, dtype = make_model(name, device)
+    if frames is not None:
+        n = int(frames)
     rank = dist.get_rank() if dist else 0
     x = synthetic_frames(n, seed=2016 + rank, device=f"cuda:{device}")
     probs = torch.empty((n, m.topology.classes), dtype=torch.float32, device=x.device)
     labels = torch.empty((n,), dtype=torch.int32, device=x.device)
     from modulationdetectioncnn_amd.sharding import timed_region
+    chunk = launch_chunk(WORKLOADS[name][0], dtype, n)
+    m.bench_chunk = chunk      # (the untimed profiling pass of dominant_roofline launches the same way)
     # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps, MAX over ranks
-    el = timed_region(lambda: m.forward_device(x, probs=probs, labels=labels), steps, warmup,
+    el = timed_region(lambda: m.forward_device(x, probs=probs, labels=labels, batch_size=chunk), steps, warmup,
                       sync=torch.cuda.synchronize, device=x.device)
     return m, x, probs, labels, n, el
+
+
+def multi_gpu_legs(name, ngpu, rank):
+    """The other two readings of BASELINE.json's metric / configs at N > 1 (the headline line is weak scaling at the
+    workload's own per-GPU batch): [(label, scaling, workload, frames of this rank, global batch)]."""
+    from modulationdetectioncnn_amd.sharding import shard_range
+    kind, filters, classes, dtype, n, _ = WORKLOADS[name]
+    lo, hi = shard_range(n, rank, ngpu)
+    legs = [(f"metric read as a fixed global batch of {n} frames (strong scaling)", "strong", name, hi - lo, n)]
+    big = {"vtcnn2-c11-bf16-n2^20": "vtcnn2-c11-bf16-n2^21", "deployed3-f32-n2^20": "deployed3-f32-n2^21"}.get(name)
+    if big:
+        per = WORKLOADS[big][4]
+        legs.append((f"configs[3]: 2^24 frames over 8 GPUs = {per} per GPU (weak scaling at that shard)", "weak", big, per, per * ngpu))
+    return legs
 
 
 def run_iq_u8(filters, device, steps=20, warmup=5, n=1 << 22):
@@ -276,9 +315,10 @@ def run_q612(filters, device, steps=10, warmup=3, n=1 << 20):
     x = synthetic_frames(n, seed=2016, sigma=0.3, device=f"cuda:{device}")
     el = timed_region(lambda: m.predict_q612(x, as_float=False), steps, warmup, sync=torch.cuda.synchronize, device=x.device)
     gbs = (1024 + 16) * n * steps / el / 1e9
+    traffic, tsrc = measured_traffic(f"mdc_deployed_q612/F{filters}", n)
     return {"workload": f"deployed{filters}-q612-n2^20", "value": n * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
             "dtype": "int18/int32 (Q6.12)", "roofline": {"bound": "int-valu", "kernel": "mdc_deployed_q612", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": measured_traffic(f"mdc_deployed_q612/F{filters}", n),
+                                                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
                                                         "from": "wall time incl. two small output allocations, one launch per step; HBM fraction reported, the bound is 64-bit integer VALU"}}
 
 
@@ -387,7 +427,8 @@ def main(argv=None):
         "data": "synthetic N(0,5e-3) f32 frames resident in HBM; " + weights,
         "config": {"workload": name, "topology": kind, "classes": classes, "frames_per_gpu": n,
                    "global_batch": n * ngpu, "parallelism": f"batch-shard x{ngpu} (no collective)",
-                   "outputs": "softmax probabilities f32 + argmax int32"},
+                   "outputs": "softmax probabilities f32 + argmax int32",
+                   "frames_per_forward_call": launch_chunk(kind, dtype, n) or "library default"},
     }
     if rank == 0:
         rl, kernels = dominant_roofline(m, x, probs, labels, max(2, min(args.steps, 5)))
@@ -395,6 +436,21 @@ def main(argv=None):
         out["kernels"] = kernels
     del m, x, probs, labels
     torch.cuda.empty_cache()
+    if dist and ngpu > 1:      # every rank runs these (barriers inside timed_region); rank 0 reports
+        legs = []
+        for label, scaling, wl, frames, global_batch in multi_gpu_legs(name, ngpu, rank):
+            lsteps, lwarm = max(1, min(args.steps, 5)), min(args.warmup, 2)
+            try:
+                lm, lx, lp, ll, ln, lel = run_workload(wl, device, lsteps, lwarm, dist, frames=frames)
+                legs.append({"workload": wl, "reading": label, "scaling": scaling, "n_gpus": ngpu, "global_batch": global_batch,
+                             "frames_per_gpu": global_batch // ngpu, "value": global_batch * lsteps / lel, "unit": "frames/s",
+                             "ms_per_step": lel / lsteps * 1e3, "steps": lsteps, "warmup": lwarm, "dtype": WORKLOADS[wl][3]})
+                del lm, lx, lp, ll
+                torch.cuda.empty_cache()
+            except Exception as e:      # an extra leg never hides the headline (every rank raises or none: same code path)
+                legs.append({"workload": wl, "reading": label, "error": repr(e)})
+        if rank == 0:
+            out["extra"] = legs
     if rank == 0 and ngpu == 1:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name)
@@ -434,7 +490,7 @@ def main(argv=None):
                 extras.append(run_host_path(device))
             except Exception as e:
                 extras.append({"workload": "host-resident input", "error": repr(e)})
-            out["extra"] = extras
+            out["extra"] = out.get("extra", []) + extras
     if dist:
         dist.barrier()
         dist.destroy_process_group()

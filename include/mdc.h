@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define MDC_ABI_VERSION 2   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows */
+#define MDC_ABI_VERSION 3   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows
+                               3: mdc_topology.reserved[0] carries MDC_OPT_* bits (additive: 0 = the behaviour of 2) */
 
 /* error codes (negative errno values) */
 #define MDC_OK        0
@@ -79,8 +80,17 @@ typedef struct mdc_topology {
     int32_t filters;     /* deployed: F (3 or 10); cnnpy: F (10); vtcnn2: ignored (256/80)    */
     int32_t hidden;      /* cnnpy: D (10); vtcnn2: ignored (256); deployed: ignored           */
     int32_t classes;     /* C                                                                */
-    int32_t reserved[4]; /* must be 0                                                        */
+    int32_t reserved[4]; /* [0]: option bits MDC_OPT_* (0 = defaults); [1..3] must be 0      */
 } mdc_topology;
+
+/* Option bits (mdc_topology.reserved[0]; validated by mdc_create, fixed for the model's life).
+ * MDC_OPT_KERAS_CONV_ORDER  deployed 10-filter net at f32: evaluate the conv as Keras does (two fmas + max per
+ *                           output) instead of the re-associated "pivot" form mdc_finalize otherwise chooses when
+ *                           every second tap is non-zero (one fma + one v_med3, sign/scale folded into the dense
+ *                           weights; same function within 2e-6 of the probabilities, 7-9 % faster).  The 3-filter
+ *                           net -- the one whose output is pinned to Keras' recorded vector -- always runs Keras' order. */
+#define MDC_OPT_KERAS_CONV_ORDER 1
+#define MDC_OPT_ALL 1
 
 typedef struct mdc_model mdc_model;   /* opaque, owned by the library */
 
@@ -107,7 +117,13 @@ int mdc_finalize(mdc_model* m, int dtype);
  * reference's bundled frames).  It fixes the power-of-two scale of the fp8 activations. */
 int mdc_set_fp8_input_absmax(mdc_model* m, float absmax);
 
-/* Bytes of caller-owned device scratch mdc_forward needs for n frames (0 for deployed). */
+/* Bytes of caller-owned device scratch ONE mdc_forward call of n frames needs (0 for deployed / cnnpy).
+ * MDC_KIND_VTCNN2 keeps a call's conv2 features there: n rounded up to 256 frames x (10,560 features x 2 B in the
+ * bf16 / fp8 modes, 4 B at f32, + 1 KiB of hidden layer) = 22,144 B (f32: 43,264 B) per frame -- 1.45 GB for a
+ * 65,536-frame call, 23.2 GB for a 2^20-frame one.  The cost is PER CONCURRENT CALL: forwards enqueued on different
+ * streams must not share a workspace.  A caller bounds it by splitting a batch into several calls (results do not
+ * depend on the split; 65,536 frames per call already fill the chip 16 times over and cost 1.5 % against one
+ * 2^20-frame call); modulationdetectioncnn_amd.VTCNN2 does that by default. */
 size_t mdc_workspace_bytes(const mdc_model* m, int64_t n);
 
 /* model.predict(X) (+ np.argmax): x_dev (n,2,128) f32 contiguous on the model's device.
@@ -153,6 +169,7 @@ int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_
  * hop = MDC_HOP_FRAME (128) is mdc_iq_u8_to_frames.  x_dev (n,2,128) f32.  Runs on the current device. */
 #define MDC_HOP_FRAME 128
 int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale, float* x_dev, void* hip_stream);
+/* (iq_dev 2-byte aligned -- whole (I,Q) pairs --, as mdc_forward_iq_u8 requires; otherwise MDC_EINVAL) */
 
 /* Conversion and forward in ONE pass, for the deployed nets (any of their dtypes) and the VT-CNN2 family (f32, bf16,
  * fp8): the forward kernel itself reads the raw bytes (the deployed kernels' loads / LDS-DMA, the VT-CNN2 conv

@@ -11,6 +11,10 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdc.so")
+# "alternates" = the -DMDC_ALTERNATES test build (build.py): the product kernels plus the measured-slower alternates the
+# GPU suite holds them against.  Tests ask for it by name; nothing in the package does.
+LIB_PATHS = {"product": LIB_PATH, "alternates": os.path.join(_HERE, "libmdc_alt.so")}
+OPT_KERAS_CONV_ORDER = 1
 
 KIND_DEPLOYED, KIND_VTCNN2, KIND_CNNPY = 1, 2, 3
 F32, BF16, FP8, F16 = 0, 1, 2, 3
@@ -23,7 +27,7 @@ EXPORTS = [
     "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax",
     "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 HOP_FRAME = 128
 
 
@@ -38,19 +42,19 @@ class MdcError(RuntimeError):
         self.code = code
 
 
-_lib: Optional[C.CDLL] = None
+_libs: dict = {}
 
 
-def lib() -> C.CDLL:
+def lib(variant: str = "product") -> C.CDLL:
     """Load libmdc.so (once).  Raises if the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if variant in _libs:
+        return _libs[variant]
+    path = LIB_PATHS[variant]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m modulationdetectioncnn_amd.build` "
+            f"{path} is missing: build it with `python -m modulationdetectioncnn_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
     L.mdc_abi_version.restype = i32
     L.mdc_create.argtypes = [C.POINTER(MdcTopology), i32, C.POINTER(vp)]
@@ -85,12 +89,12 @@ def lib() -> C.CDLL:
                  "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8"):
         getattr(L, name).restype = i32
     if L.mdc_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"libmdc.so ABI version {L.mdc_abi_version()} != {ABI_VERSION}; rebuild it")
-    _lib = L
+        raise RuntimeError(f"{os.path.basename(path)} ABI version {L.mdc_abi_version()} != {ABI_VERSION}; rebuild it")
+    _libs[variant] = L
     return L
 
 
-def check(rc: int) -> int:
+def check(rc: int, variant: str = "product") -> int:
     if rc < 0:
-        raise MdcError(rc, lib().mdc_last_error().decode("utf-8", "replace"))
+        raise MdcError(rc, lib(variant).mdc_last_error().decode("utf-8", "replace"))
     return rc

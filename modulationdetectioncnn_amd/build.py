@@ -21,11 +21,18 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libmdc.so")
 ARCH = "gfx950"
+# Two libraries come out of the same sources:
+#   "product"     libmdc.so      one kernel per role; nothing under mdc_forward* reads the environment
+#   "alternates"  libmdc_alt.so  -DMDC_ALTERNATES: additionally the measured-slower alternate kernels that the GPU suite
+#                                uses as bit-identity / race screens (the hipcc-scheduled bf16 conv, the one-barrier
+#                                dense1, the deployed nets' f32-MFMA dense layer, the head as its own launch), selected
+#                                per model by environment variables that mdc_create reads once
+VARIANTS = {"product": (OBJ, LIB, ()),
+            "alternates": (os.path.join(HERE, "csrc", "build_alt"), os.path.join(HERE, "libmdc_alt.so"), ("-DMDC_ALTERNATES",))}
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"),
             "-I", CSRC, "-Wall", "-Wno-unused-function", "-pthread"]
 # (no -fno-exceptions: the C ABI catches std::bad_alloc & co. at the boundary and returns MDC_ENOMEM, mdc_api.hip)
-STAMP = os.path.join(OBJ, "flags.stamp")
 
 
 def _hipcc() -> str:
@@ -46,20 +53,30 @@ def _newer(a: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def flag_key(extra_flags=()) -> str:
+    return hashlib.sha256(" ".join([*CXXFLAGS, *extra_flags]).encode()).hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: str = "product") -> str:
+    obj_dir, lib_path, vflags = VARIANTS[variant]
+    extra_flags = (*vflags, *extra_flags)
+    os.makedirs(obj_dir, exist_ok=True)
+    stamp = os.path.join(obj_dir, "flags.stamp")
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "mdc.h")]
-    flag_key = hashlib.sha256(" ".join([*CXXFLAGS, *extra_flags]).encode()).hexdigest()
-    if not (os.path.exists(STAMP) and open(STAMP).read().strip() == flag_key):
+    key = flag_key(extra_flags)
+    if not (os.path.exists(stamp) and open(stamp).read().strip() == key):
         force = True        # objects (if any) were built with other flags
     jobs = []
     objs = []
     for src in sources():
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or not _newer(obj, [src] + headers):
             jobs.append((src, obj))
+    for f in os.listdir(obj_dir):      # an object whose source is gone (a removed kernel file) does not linger in the tree
+        if f.endswith(".o") and os.path.join(obj_dir, f) not in objs:
+            os.remove(os.path.join(obj_dir, f))
 
     def cc(job):
         src, obj = job
@@ -74,19 +91,25 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         return obj
 
     if jobs:
-        if os.path.exists(STAMP):
-            os.remove(STAMP)        # a build interrupted half way must not look complete
+        if os.path.exists(stamp):
+            os.remove(stamp)        # a build interrupted half way must not look complete
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(cc, jobs))
-    with open(STAMP, "w") as f:
-        f.write(flag_key + "\n")
-    if jobs or not _newer(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    with open(stamp, "w") as f:
+        f.write(key + "\n")
+    if jobs or not _newer(lib_path, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", lib_path, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib_path
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    """The product library and the alternates test build."""
+    return [build(force=force, verbose=verbose, variant=v) for v in VARIANTS]
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    for path in build_all(force="--force" in sys.argv, verbose="-v" in sys.argv):
+        print(path)

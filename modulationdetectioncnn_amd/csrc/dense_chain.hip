@@ -13,33 +13,15 @@
 // loads, staged in LDS, and read back as MFMA A operands (A[row][k]); every layer's weights sit in
 // registers as B operands (B[k][col]); a layer's 16x16 result (col on the lane) goes through a
 // 2 KiB LDS transpose to become the next layer's A operand.  HBM-bound: 1 KiB read per row.
-#include "mdc_internal.h"
-
-#include <cmath>
+#include "dense_chain_common.h"
 
 namespace mdc {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 namespace {
 
 constexpr int kK0 = 256;          // input width (floats per row)
-constexpr int kXld = 260;         // LDS row stride of the staged input (16-B aligned rows)
+constexpr int kXld = kChainXld;   // LDS row stride of the staged input (16-B aligned rows)
 constexpr int kYld = 36;          // LDS row stride of an inter-layer activation tile (<= 32 columns)
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// butterfly over the 16 lanes of a DPP row: afterwards every lane holds op over the row
-template <typename Op>
-__device__ __forceinline__ float row_allreduce(float v, Op op) {
-    v = op(v, dpp_mov<0xB1>(v));     // quad_perm [1,0,3,2]
-    v = op(v, dpp_mov<0x4E>(v));     // quad_perm [2,3,0,1]
-    v = op(v, dpp_mov<0x141>(v));    // row_half_mirror
-    v = op(v, dpp_mov<0x140>(v));    // row_mirror
-    return v;
-}
 
 struct ChainParams {
     const float* x;        // [n][256]
@@ -143,29 +125,7 @@ __global__ __launch_bounds__(256) void dense_chain_kernel(ChainParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = a3[r] + b3;
         }
-        // ---- softmax + first-max argmax over the classes (the 16 lanes of a DPP row) ----
-        const bool cls = fr < p.n_out;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long row = row0 + 4 * g + r;
-            const float zz = cls ? z[r] : -INFINITY;
-            const float mx = row_allreduce(zz, [](float a, float b) { return fmaxf(a, b); });
-            const float e = cls ? expf(zz - mx) : 0.f;
-            const float sum = row_allreduce(e, [](float a, float b) { return a + b; });
-            const float pv = e / sum;
-            // int(np.argmax(test_Y_hat[i,:])) (cnn.py:209): FIRST index attaining the maximum of the
-            // PROBABILITIES as returned (slightly different logits can round to the same probability)
-            const float pmx = row_allreduce(cls ? pv : -1.f, [](float a, float b) { return fmaxf(a, b); });
-            const float cand = (cls && pv == pmx) ? (float)fr : 1e9f;
-            const float arg = row_allreduce(cand, [](float a, float b) { return fminf(a, b); });
-            if (row < p.n) {
-                if (cls) {
-                    if (p.probs) p.probs[row * p.n_out + fr] = pv;
-                    if (p.tap_logits) p.tap_logits[row * p.n_out + fr] = z[r];
-                }
-                if (fr == 0 && p.labels) p.labels[row] = (int)arg;
-            }
-        }
+        chain_softmax_store(z, fr, g, row0, p.n, p.n_out, p.probs, p.labels, p.tap_logits);
     }
 }
 

@@ -414,16 +414,18 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
 
 }  // namespace
 
-// F = 10 with a pivot table: the one-fma conv form (MDC_DEP_PIVOT=0 selects the plain form, for A/B runs and its tests)
-static bool pivot_form(const mdc_model* m) {
-    if (!m->dep_pivot) return false;
-    const char* e = getenv("MDC_DEP_PIVOT");
-    return !(e && atoi(e) == 0);
-}
+// F = 10 with a pivot table: the one-fma conv form.  Whether it runs is decided ONCE, in deployed_pack (mdc_finalize):
+// the table exists and the caller did not ask for Keras' operation order (MDC_OPT_KERAS_CONV_ORDER).  Nothing under
+// mdc_forward* reads the environment.
+static bool pivot_form(const mdc_model* m) { return m->dep_pivot; }
 
-static bool f32_mfma_variant() {
-    const char* e = getenv("MDC_DEP_F32_MFMA");
-    return e && atoi(e) != 0;
+static bool f32_mfma_variant(const mdc_model* m) {
+#ifdef MDC_ALTERNATES
+    return (m->alt & kAltDepF32Mfma) != 0;
+#else
+    (void)m;
+    return false;
+#endif
 }
 
 // Pack: [F x (k0,k1,b)] [bd x3] pad to 64 floats, then per-lane dense weights
@@ -456,7 +458,7 @@ int deployed_pack(mdc_model* m) {
     // the pivot table (F = 10 only; see deployed_fwd_kernel): needs every K1[f] != 0 with a ratio K0/K1 that stays a normal
     // float -- otherwise slot 6 stays empty and the plain form runs
     m->dep_pivot = false;
-    if (F == 10) {
+    if (F == 10 && !(m->topo.reserved[0] & MDC_OPT_KERAS_CONV_ORDER)) {
         bool ok = true;
         for (int f = 0; f < F; ++f) {
             const double k0 = ck[0 * F + f], k1 = ck[1 * F + f];
@@ -501,7 +503,11 @@ int deployed_pack(mdc_model* m) {
             m->dep_pivot = true;
         }
     }
+#ifdef MDC_ALTERNATES
     return deployed_f32m_pack(m);      // + the dense layer as f32 MFMA operands (deployed_f32m.hip)
+#else
+    return MDC_OK;
+#endif
 }
 
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
@@ -518,11 +524,13 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
     float* tap_conv = (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) ? tap : nullptr;
     float* tap_dense = (tap_kind == MDC_TAP_DENSE) ? tap : nullptr;
     ProfScope ps(m, 0, s);
-    // MDC_DEP_F32_MFMA=1 (read per call; A/B measurement and its parity tests) selects the variant with Dense(3) on the
-    // f32 matrix pipe (deployed_f32m.hip: same results to the last bits of the summation order, measured SLOWER --
-    // v_mfma_f32_4x4x1 holds the SIMD's vector issue for its whole 8 cycles); the production f32
-    // path is the all-VALU kernel below.  Conv/flat taps always use the simple one-frame-at-a-time kernel.
-    if (!tap_conv && f32_mfma_variant()) return deployed_f32m_forward(m, x, n, probs, labels, tap_dense, s);
+    // Alternates build only (MDC_DEP_F32_MFMA=1 when the model was created): the variant with Dense(3) on the f32 matrix
+    // pipe (deployed_f32m.hip: same results to the last bits of the summation order, measured SLOWER -- v_mfma_f32_4x4x1
+    // holds the SIMD's vector issue for its whole 8 cycles); the production f32 path is the
+    // all-VALU kernel below.  Conv/flat taps always use the simple one-frame-at-a-time kernel.
+#ifdef MDC_ALTERNATES
+    if (!tap_conv && f32_mfma_variant(m)) return deployed_f32m_forward(m, x, n, probs, labels, tap_dense, s);
+#endif
     const long nfull = tap_conv ? 0 : (n / 64) * 64;      // frames handled by the fast kernel
     if (nfull > 0) {
         long grid = (nfull / 64 + 3) / 4;
@@ -589,7 +597,9 @@ int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int
     const long hop2 = 2 * (long)hop;
     const float* xb = reinterpret_cast<const float*>(iq);
     ProfScope ps(m, 0, s);
-    if (f32_mfma_variant()) return deployed_f32m_forward_iq_u8(m, iq, n, hop2, scale, probs, labels, s);
+#ifdef MDC_ALTERNATES
+    if (f32_mfma_variant(m)) return deployed_f32m_forward_iq_u8(m, iq, n, hop2, scale, probs, labels, s);
+#endif
     if (nfull > 0) {
         long grid = (nfull / 64 + 3) / 4;
         if (grid > 2048) grid = 2048;

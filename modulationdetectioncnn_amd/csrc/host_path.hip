@@ -32,8 +32,15 @@ constexpr int kCopyThreads = 4;                     // 2 reach 50 GB/s, 4 the DM
 // A few helper threads that live for one call and split each staging memcpy with the calling thread.
 class CopyPool {
 public:
+    // A helper that cannot be started (EAGAIN under a thread limit: std::system_error) is simply not there: the pool runs
+    // with the helpers it got -- or none, the caller copies alone -- and never unwinds with joinable threads in th_
+    // (a half-built pool's destructor does not run: std::terminate, which the ABI's catch-all cannot stop).
     explicit CopyPool(int helpers) {
-        for (int i = 0; i < helpers; ++i) th_.emplace_back([this, i] { run(i); });
+        try {
+            th_.reserve(helpers > 0 ? (size_t)helpers : 0);
+            for (int i = 0; i < helpers; ++i) th_.emplace_back([this, i] { run(i); });
+        } catch (...) {
+        }
     }
     ~CopyPool() {
         {
@@ -205,11 +212,14 @@ int ctx_prepare(mdc_model* m, size_t in_bytes, int64_t frames) {
 }
 
 // (the first byte decides: a caller that pins its buffer pins all of it)
-bool is_pinned(const void* p) {
+// 0 = pageable host memory (or unknown to HIP), 1 = pinned host memory, -1 = DEVICE memory: not a host buffer at all
+int host_kind(const void* p) {
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (a.type == hipMemoryTypeDevice) return -1;
+    return a.type == hipMemoryTypeHost ? 1 : 0;
 }
+bool is_pinned(const void* p) { return host_kind(p) == 1; }
 
 // in_range(start, count) -> (byte offset, byte count) of the input those windows read; launch(d_in, count, slot, ctx)
 template <class InRange, class Launch>
@@ -288,6 +298,9 @@ int check_common(const char* who, const mdc_model* m, const void* in, int64_t n,
     if (n < 0) { set_error("%s: negative frame count", who); return MDC_EINVAL; }
     if (chunk < 0) { set_error("%s: negative chunk size", who); return MDC_EINVAL; }
     if (n > 0 && !in) { set_error("%s: null input", who); return MDC_EINVAL; }
+    // a device pointer here would be handed to memcpy by the staging threads: these entry points take HOST buffers
+    // (frames already in HBM go to mdc_forward / mdc_forward_iq_u8)
+    if (n > 0 && host_kind(in) < 0) { set_error("%s: the input lies in device memory; use mdc_forward / mdc_forward_iq_u8 for it", who); return MDC_EINVAL; }
     return MDC_OK;
 }
 

@@ -2,6 +2,7 @@
 // each entry point replaces).  No torch types, no exceptions across the boundary.
 #include "mdc_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <mutex>
@@ -120,7 +121,8 @@ int mdc_create(const mdc_topology* topo, int device, mdc_model** out) {
     return guarded("mdc_create", [&]() -> int {
         if (!topo || !out) { set_error("mdc_create: null argument"); return MDC_EINVAL; }
         *out = nullptr;
-        for (int r : topo->reserved) if (r != 0) { set_error("mdc_create: reserved fields must be 0"); return MDC_EINVAL; }
+        if ((topo->reserved[0] & ~MDC_OPT_ALL) != 0) { set_error("mdc_create: unknown option bits 0x%x in reserved[0]", topo->reserved[0]); return MDC_EINVAL; }
+        for (int i = 1; i < 4; ++i) if (topo->reserved[i] != 0) { set_error("mdc_create: reserved[1..3] must be 0"); return MDC_EINVAL; }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MDC_ENODEV; }
         if (device < 0 || device >= ndev) { set_error("device %d out of range (have %d)", device, ndev); return MDC_ENODEV; }
@@ -134,6 +136,15 @@ int mdc_create(const mdc_topology* topo, int device, mdc_model** out) {
         if (!m) { set_error("out of host memory"); return MDC_ENOMEM; }
         m->topo = *topo;
         m->device = device;
+#ifdef MDC_ALTERNATES      // the test build: which alternate kernels this model runs, read once, here
+        {
+            auto flag = [](const char* name, int when) { const char* e = getenv(name); return e && atoi(e) == when; };
+            if (flag("MDC_CONV_SCHED", 0)) m->alt |= kAltConvHipcc;
+            if (flag("MDC_DENSE1_PHASED", 0)) m->alt |= kAltDense1Simple;
+            if (flag("MDC_DEP_F32_MFMA", 1)) m->alt |= kAltDepF32Mfma;
+            if (flag("MDC_D1_FUSED_HEAD", 0)) m->alt |= kAltSeparateHead;
+        }
+#endif
         int rc = MDC_ENOMEM;
         try { rc = layer_layout(m); } catch (...) { delete m; throw; }
         if (rc != MDC_OK) { delete m; return rc; }
@@ -290,7 +301,8 @@ int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, 
     if (n < 0) { set_error("mdc_confusion: negative count"); return MDC_EINVAL; }
     if (n > 0 && (!truth_dev || !pred_dev)) { set_error("mdc_confusion: null labels"); return MDC_EINVAL; }
     if (!counts_dev) { set_error("mdc_confusion: null counts"); return MDC_EINVAL; }
-    return confusion_launch(truth_dev, pred_dev, nullptr, n, classes, 1, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream));
+    return guarded("mdc_confusion", [&]() -> int {
+        return confusion_launch(truth_dev, pred_dev, nullptr, n, classes, 1, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream)); });
 }
 
 int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, const int32_t* bin_dev, int64_t n, int classes, int bins,
@@ -299,7 +311,8 @@ int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, cons
     if (n > 0 && (!truth_dev || !pred_dev || !bin_dev)) { set_error("mdc_confusion_binned: null labels"); return MDC_EINVAL; }
     if (!counts_dev) { set_error("mdc_confusion_binned: null counts"); return MDC_EINVAL; }
     if (bins < 1) { set_error("mdc_confusion_binned: bins must be >= 1 (got %d)", bins); return MDC_EINVAL; }
-    return confusion_launch(truth_dev, pred_dev, bin_dev, n, classes, bins, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream));
+    return guarded("mdc_confusion_binned", [&]() -> int {
+        return confusion_launch(truth_dev, pred_dev, bin_dev, n, classes, bins, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream)); });
 }
 
 int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream) {
@@ -310,7 +323,7 @@ int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_
         set_error("mdc_iq_u8_to_frames: iq must be 4-byte and frames 8-byte aligned");
         return MDC_EINVAL;
     }
-    return iq_u8_launch(iq_dev, n, 128, scale, x_dev, static_cast<hipStream_t>(hip_stream));
+    return guarded("mdc_iq_u8_to_frames", [&]() -> int { return iq_u8_launch(iq_dev, n, 128, scale, x_dev, static_cast<hipStream_t>(hip_stream)); });
 }
 
 int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale, float* x_dev, void* hip_stream) {
@@ -319,7 +332,9 @@ int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale
     if (n == 0) return MDC_OK;
     if (!iq_dev || !x_dev) { set_error("mdc_iq_u8_windows: null buffer"); return MDC_EINVAL; }
     if ((reinterpret_cast<uintptr_t>(x_dev) & 7) != 0) { set_error("mdc_iq_u8_windows: frames must be 8-byte aligned"); return MDC_EINVAL; }
-    return iq_u8_launch(iq_dev, n, hop, scale, x_dev, static_cast<hipStream_t>(hip_stream));
+    // as mdc_forward_iq_u8 (whose result this call + mdc_forward must equal): whole (I,Q) pairs, i.e. 2-byte alignment
+    if ((reinterpret_cast<uintptr_t>(iq_dev) & 1) != 0) { set_error("mdc_iq_u8_windows: input must start on a whole (I,Q) pair (2-byte aligned)"); return MDC_EINVAL; }
+    return guarded("mdc_iq_u8_windows", [&]() -> int { return iq_u8_launch(iq_dev, n, hop, scale, x_dev, static_cast<hipStream_t>(hip_stream)); });
 }
 
 int mdc_set_profiling(mdc_model* m, int on) {

@@ -44,6 +44,12 @@ __device__ __forceinline__ uint2 load8_unaligned(const unsigned char* p) {
     return r;
 }
 
+// alternates (test build only, see mdc_model::alt)
+enum { kAltConvHipcc = 1,      // MDC_CONV_SCHED=0: the hipcc-scheduled statement of the bf16 conv kernel (vtcnn2_bf16.hip)
+       kAltDense1Simple = 2,   // MDC_DENSE1_PHASED=0: one barrier per K-tile (the race screen of the phased kernel)
+       kAltDepF32Mfma = 4,     // MDC_DEP_F32_MFMA=1: deployed nets' f32 dense layer on the f32 matrix pipe (deployed_f32m.hip)
+       kAltSeparateHead = 8 }; // MDC_D1_FUSED_HEAD=0: dense2 + softmax as their own launch at every batch size
+
 struct ProfSlot {
     const char* name;
     std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -69,7 +75,11 @@ struct mdc_model {
 
     // fp8 mode (vtcnn2): largest |sample| the caller expects (sets the activation scale) and the resulting
     // power-of-two scale of the features, 2^fp8_feat_scale_log2 (vtcnn2_fp8_conv.hip)
-    bool dep_pivot = false;      // deployed F = 10: the pivot-form table (d_pack[6]) exists (deployed.hip)
+    bool dep_pivot = false;      // deployed F = 10: the pivot-form table (d_pack[6]) exists AND is the form that runs (deployed.hip)
+    // Alternate kernels exist only in the -DMDC_ALTERNATES test build (libmdc_alt.so); there mdc_create reads the
+    // selecting environment variables ONCE into this field (mdc::kAlt* bits).  Always 0 in the product library: no entry
+    // point under mdc_forward* reads the environment.
+    int alt = 0;
     float fp8_input_absmax = 0.02f;
     int fp8_feat_scale_log2 = 0;
 
@@ -122,7 +132,7 @@ void host_ctx_free(mdc_model* m);
 
 // ---- deployed (T1/T2): deployed.hip -------------------------------------------------
 int deployed_pack(mdc_model* m);
-// f32 with the dense layer on the f32 matrix pipe (production f32 path): deployed_f32m.hip
+// f32 with the dense layer on the f32 matrix pipe (measured slower: alternates build only): deployed_f32m.hip
 int deployed_f32m_pack(mdc_model* m);
 int deployed_f32m_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels, float* tap_dense, hipStream_t s);
 int deployed_f32m_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, long hop2, float scale, float* probs, int32_t* labels, hipStream_t s);

@@ -323,7 +323,8 @@ int chain_launch(int t1, int nl, const float* x, long n, const float* wpack, int
 // ---- bf16 entry points (vtcnn2_bf16.hip) ------------------------------------------------
 int vtcnn2_bf16_pack(mdc_model* m);
 int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2 = 0, float scale = 0.f);
-int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s);
+int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s,
+                       bool fuse_head, float* probs, int32_t* labels, bool* fused);
 
 // d_pack slots: 0 conv2 weights, 1 conv1 operand, 2 conv2 bias, 3 dense1 weights (permuted),
 //               4 dense1 bias, 5 head (dense2) pack for dense_chain
@@ -397,9 +398,11 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
     float* hid = reinterpret_cast<float*>(static_cast<char*>(ws) + fbytes);
     const int C = m->topo.classes;
     int rc;
+    bool head_done = false;      // dense2 + softmax + argmax already ran in dense1's epilogue (16-bit modes, batch kernels, no dense/hidden tap)
     if (m->dtype == MDC_BF16 || m->dtype == MDC_FP8) {
         { ProfScope ps(m, 0, s); if ((rc = m->dtype == MDC_FP8 ? vtcnn2_fp8_conv(m, x, n, feat, s, hop2, scale) : vtcnn2_bf16_conv(m, x, n, feat, s, hop2, scale))) return rc; }
-        { ProfScope ps(m, 1, s); if ((rc = vtcnn2_bf16_dense1(m, feat, n, hid, s))) return rc; }
+        const bool fuse = tap_kind != MDC_TAP_DENSE && tap_kind != MDC_TAP_HIDDEN;
+        { ProfScope ps(m, 1, s); if ((rc = vtcnn2_bf16_dense1(m, feat, n, hid, s, fuse, probs, labels, &head_done))) return rc; }
     } else {
         {
             ProfScope ps(m, 0, s);
@@ -440,7 +443,7 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
             MDC_HIP(hipGetLastError());
         }
     }
-    {
+    if (!head_done) {
         ProfScope ps(m, 2, s);
         if ((rc = chain_launch(1, 1, hid, (long)n, static_cast<const float*>(m->d_pack[5]), C, 0, 0, probs, labels,
                                tap_kind == MDC_TAP_DENSE ? tap : nullptr, nullptr, nullptr, 0, 0, s)))

@@ -33,6 +33,7 @@ namespace mdc {
 
 namespace {
 
+#ifdef MDC_ALTERNATES      // the hipcc-scheduled statement of the algorithm: 36 % slower than the asm-sequenced kernel; test build only
 __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __restrict__ x, long n,
                                                               const u32x4* __restrict__ wq,   // [4][60][64]
                                                               const u32x2* __restrict__ a1q,  // [4][4][64]
@@ -261,6 +262,8 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
 }
 
 
+#endif  // MDC_ALTERNATES
+
 }  // namespace
 
 int vtcnn2_bf16_pack(mdc_model* m) {
@@ -268,6 +271,7 @@ int vtcnn2_bf16_pack(mdc_model* m) {
     const float* b1 = m->hb[0].data();
     const float* k2 = m->hk[1].data();   // (80,256,2,3)
     int rc;
+#ifdef MDC_ALTERNATES      // operands of the hipcc-scheduled conv kernel (d_pack slots 0 and 1): test build only
     // conv2 A-fragments: [q][((h*3+j)*2+cp)*5+ot][lane][8]; lane (o' = lane&15, g = lane>>4) slot jj holds
     // K2[16ot+o'][64q + 32cp + (jj<4 ? 4g+jj : 16+4g+jj-4)][h][j]   (the channel order X arrives in)
     std::vector<unsigned short> wq((size_t)4 * kWFrags * 64 * 8);
@@ -305,6 +309,10 @@ int vtcnn2_bf16_pack(mdc_model* m) {
                 }
             }
     if ((rc = upload(m, 1, a1.data(), a1.size() * 2))) return rc;
+    (void)k1; (void)b1; (void)k2;
+#else
+    (void)k1; (void)b1; (void)k2;
+#endif
     // dense1: transposed and K-tiled [k'/64][n][k'%64] with k' = w*80 + o  <-  reference row o*132 + w
     const float* w1 = m->hk[2].data();
     std::vector<unsigned short> w1t((size_t)kHid * kFeat);
@@ -320,18 +328,21 @@ int vtcnn2_bf16_pack(mdc_model* m) {
 }
 
 int vtcnn2_bf16_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2, float scale) {
-    // default: the asm-sequenced kernel (vtcnn2_bf16_sched.hip); MDC_CONV_SCHED=0 selects the hipcc-scheduled one
-    // (same results up to summation order) for A/B timing (f32 frames only: raw bytes always take the production kernel)
-    static const bool sched = !(getenv("MDC_CONV_SCHED") && atoi(getenv("MDC_CONV_SCHED")) == 0);
-    if (sched || hop2 > 0) return vtcnn2_bf16_conv_sched(m, x, n, feat, s, hop2, scale);
-    const long ngroups = (n + 15) / 16;
-    const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds));
-    hipLaunchKernelGGL(vt_conv_bf16_kernel, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n,
-                       static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]),
-                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat));
-    MDC_HIP(hipGetLastError());
-    return MDC_OK;
+    // the asm-sequenced kernel (vtcnn2_bf16_sched.hip).  Alternates build, model created under MDC_CONV_SCHED=0: the
+    // hipcc-scheduled one (same results up to summation order), f32 frames only -- raw bytes always take the production kernel
+#ifdef MDC_ALTERNATES
+    if ((m->alt & kAltConvHipcc) && hop2 <= 0) {
+        const long ngroups = (n + 15) / 16;
+        const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvBf16Lds));
+        hipLaunchKernelGGL(vt_conv_bf16_kernel, dim3(grid), dim3(256), kConvBf16Lds, s, x, (long)n,
+                           static_cast<const u32x4*>(m->d_pack[0]), static_cast<const u32x2*>(m->d_pack[1]),
+                           static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat));
+        MDC_HIP(hipGetLastError());
+        return MDC_OK;
+    }
+#endif
+    return vtcnn2_bf16_conv_sched(m, x, n, feat, s, hop2, scale);
 }
 
 }  // namespace mdc

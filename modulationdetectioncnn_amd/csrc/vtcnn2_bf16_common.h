@@ -100,6 +100,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {      // non-temporal source (read once)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 // The same copy issued from inline asm (M0 = the wave's LDS destination through the "{m0}" constraint).  hipcc tracks a
 // builtin LDS-DMA as an asynchronous LDS store and, having no alias scopes to tell ring slots apart, puts an
 // s_waitcnt vmcnt(0) in front of EVERY later LDS read -- so a ring of several groups "in flight" drained completely at

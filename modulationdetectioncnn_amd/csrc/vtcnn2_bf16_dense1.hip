@@ -7,6 +7,7 @@
 //                                 not overlap (tools/ablate_dense1.py).  Kept as the race screen (MDC_DENSE1_PHASED=0).
 //   vt_dense1_bf16_phased_kernel  the production kernel; see the comment above it.
 #include "vtcnn2_bf16_common.h"
+#include "dense_chain_common.h"
 
 #include <cstdlib>
 
@@ -20,9 +21,12 @@ namespace {
 constexpr int kBM = 256, kBN = 256, kBK = 64;
 constexpr int kTileBytes = kBM * kBK * 2;                     // 32 KiB per operand tile
 constexpr size_t kDenseBf16Lds = (size_t)4 * kTileBytes;      // A,B x 2 buffers = 128 KiB
+constexpr size_t kDenseHeadLds = (size_t)128 * kChainXld * 4;  // fused head: [128 rows][260] f32 image of a wave row's hidden tile (133,120 B)
+static_assert(kDenseHeadLds >= kDenseBf16Lds, "the fused-head form allocates the larger of the two");
 constexpr int kNT = kFeat / kBK;                              // 165 K-tiles
 
 
+#if defined(MDC_ALTERNATES) || defined(MDC_ABLATIONS)      // the race screen of the phased kernel: test / probe builds only
 template <int ABL>   // 0 = product; 1..3 = timing-only probes (tools/ablate_dense1.py, -DMDC_ABLATIONS; results wrong)
 __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned short* __restrict__ feat, long n,
                                                              const unsigned short* __restrict__ w1t,   // [165 k-tiles][256][64] bf16
@@ -122,6 +126,8 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned shor
 }
 
 
+#endif
+
 // ------------------------------------------------------------------------------------
 // vt_dense1_bf16_phased_kernel -- the same 256x256x64 tiles and the same accumulation order (bit-identical results),
 // restructured after the "8-phase" schedule of cdna_hip_programming.md section 5:
@@ -139,10 +145,20 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_kernel(const unsigned shor
 // ------------------------------------------------------------------------------------
 constexpr int kUnitBytes = 128 * 128;      // 128 rows x 64 bf16
 
-template <int ABL>   // 0 = product; 1 = timing-only probe: every work-group streams the same A rows (L2 hits)
+// Round 3: (1) the feature rows (read exactly once) are fetched non-temporally -- 4.70 -> 4.50 ms per 2^20 frames, the
+// weights keep the L2 to themselves; fetching every unit seven phases ahead instead of four (80 KiB in flight per CU,
+// vmcnt(10)) did NOT help (4.71-4.84 ms): the stream is not latency-bound (profiles/r03_d1_prefetch_nt_ab.log).
+// (2) HEAD = true fuses dense2 + softmax + argmax (the mdc_vt_head launch) into the epilogue: a work-group holds all 256
+// hidden units of its 256 frames, so each wave row in turn puts its half of the hidden tile (bias + ReLU applied) into
+// LDS in the head kernel's [row][260] image and every wave runs the head's own 64-step v_mfma_f32_16x16x4_f32 chain and
+// softmax code (dense_chain_common.h) on one 16-row tile -- same operands, same order, same bits as the separate launch;
+// the 1 KiB/frame hidden layer is then neither written to HBM nor read back.
+template <int ABL, bool HEAD = false>   // ABL 0 = product; 1 = timing-only probe: every work-group streams the same A rows (L2 hits)
 __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsigned short* __restrict__ feat, long n,
                                                                     const unsigned short* __restrict__ w1t,   // [165][256][64]
-                                                                    const float* __restrict__ c1, float* __restrict__ hid) {
+                                                                    const float* __restrict__ c1, float* __restrict__ hid,
+                                                                    const float* __restrict__ w2pack = nullptr, int n_out = 0,
+                                                                    float* __restrict__ probs = nullptr, int* __restrict__ labels = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 buffers][4 units][16 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,9 +185,13 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
     }
     auto stage_unit = [&](int t, int unit, int b) {
         unsigned char* dst = smem + ((size_t)b * 4 + unit) * kUnitBytes + (wv * 2) * 1024;
-        const long koff = (unit == 0 || unit == 3) ? (long)t * kBK : (long)t * (kBN * kBK);
-        glds16(src[unit][0] + koff, dst);
-        glds16(src[unit][1] + koff, dst + 1024);
+        if (unit == 0 || unit == 3) {      // feature rows: read once, non-temporal
+            glds16_nt(src[unit][0] + (long)t * kBK, dst);
+            glds16_nt(src[unit][1] + (long)t * kBK, dst + 1024);
+        } else {                           // weights: re-read by every work-group, from L2
+            glds16(src[unit][0] + (long)t * (kBN * kBK), dst);
+            glds16(src[unit][1] + (long)t * (kBN * kBK), dst + 1024);
+        }
     };
 
     // ---- fragment read offsets inside a unit (bytes): row u, 16-B chunk (ks*4 + fg) ^ (u & 7)
@@ -277,17 +297,52 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
 #undef D1_WAIT_BARRIER
 #undef D1_LGKM
 
+    if constexpr (!HEAD) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = wc * 64 + j * 16 + fr;
-        const float bias = c1[col];
+        for (int j = 0; j < 4; ++j) {
+            const int col = wc * 64 + j * 16 + fr;
+            const float bias = c1[col];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = row0 + wr * 128 + i * 16 + fg * 4 + r;
-                if (row < n) hid[row * kHid + col] = fmaxf(acc[i][j][r] + bias, 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const long row = row0 + wr * 128 + i * 16 + fg * 4 + r;
+                    if (row < n) hid[row * kHid + col] = fmaxf(acc[i][j][r] + bias, 0.f);
+                }
+        }
+    } else {
+        // ---- fused head.  No LDS-DMA is in flight here (the last tile waited vmcnt(0)) and every wave is past its last
+        // fragment read once it has passed the barrier below: the staging buffers become the [128][260] f32 image
+        float* xs = reinterpret_cast<float*>(smem);
+        float w2[64];                                  // dense2 as B operands, the head kernel's packing (chain_pack_layer)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) w2[i] = w2pack[i * 64 + lane];
+        const float b2 = w2pack[64 * 64 + 16 * 64 + fr];
+        float bias1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias1[j] = c1[wc * 64 + j * 16 + fr];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (wr == half) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            xs[(i * 16 + fg * 4 + r) * kChainXld + wc * 64 + j * 16 + fr] = fmaxf(acc[i][j][r] + bias1[j], 0.f);
             }
+            __syncthreads();
+            f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(wv * 16 + fr) * kChainXld + 4 * i + fg], w2[i], a2, 0, 0, 0);
+            f32x4 z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = a2[r] + b2;
+            chain_softmax_store(z, fr, fg, row0 + half * 128 + wv * 16, n, n_out, probs, labels, nullptr);
+        }
     }
 }
 
@@ -438,7 +493,11 @@ constexpr long kSmallBatch = 2048;
 
 }  // namespace
 
-int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s) {
+// probs / labels non-null and fuse_head: dense2 + softmax + argmax run in the GEMM's epilogue (*fused = true) and the hidden
+// layer is not written; otherwise (small batches, a layer tap downstream, the alternates) hid is, and the caller launches the head.
+int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s,
+                       bool fuse_head, float* probs, int32_t* labels, bool* fused) {
+    if (fused) *fused = false;
     if (n <= kCoopBatch) {
         MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         hipLaunchKernelGGL(vt_dense1_bf16_coop_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(256), kCoopLds, s,
@@ -454,37 +513,47 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
         MDC_HIP(hipGetLastError());
         return MDC_OK;
     }
+    const unsigned short* f = static_cast<const unsigned short*>(feat);
+    const unsigned short* w1t = static_cast<const unsigned short*>(m->d_pack[3]);
+    const float* c1 = static_cast<const float*>(m->d_pack[4]);
+    const dim3 grid((unsigned)((n + kBM - 1) / kBM));
+#if defined(MDC_ALTERNATES) || defined(MDC_ABLATIONS)
 #define MDC_LAUNCH_D1(A) do { \
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds)); \
-    hipLaunchKernelGGL(vt_dense1_bf16_kernel<A>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s, \
-                       static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]), \
-                       static_cast<const float*>(m->d_pack[4]), hid); } while (0)
+    hipLaunchKernelGGL(vt_dense1_bf16_kernel<A>, grid, dim3(512), kDenseBf16Lds, s, f, (long)n, w1t, c1, hid); } while (0)
+#endif
 #ifdef MDC_ABLATIONS
     static const int abl = getenv("MDC_ABLATE_D1") ? atoi(getenv("MDC_ABLATE_D1")) : 0;
-    if (abl == 11 || abl == 10) {      // the phased kernel: 10 = product, 11 = A rows from L2
+    if (abl == 11) {      // the phased kernel with its A rows from L2
         MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
-        if (abl == 11) hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<1>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
-                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]), static_cast<const float*>(m->d_pack[4]), hid);
-        else hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<0>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
-                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]), static_cast<const float*>(m->d_pack[4]), hid);
+        hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<1>, grid, dim3(512), kDenseBf16Lds, s, f, (long)n, w1t, c1, hid);
         MDC_HIP(hipGetLastError());
         return MDC_OK;
     }
-    switch (abl) { case 1: MDC_LAUNCH_D1(1); break; case 2: MDC_LAUNCH_D1(2); break; case 3: MDC_LAUNCH_D1(3); break; default: MDC_LAUNCH_D1(0); }
-#else
-    // default: the phased kernel; MDC_DENSE1_PHASED=0 selects the one-barrier-per-K-tile kernel (bit-identical results)
-    static const bool phased = !(getenv("MDC_DENSE1_PHASED") && atoi(getenv("MDC_DENSE1_PHASED")) == 0);
-    if (phased) {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
-        hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<0>, dim3((unsigned)((n + kBM - 1) / kBM)), dim3(512), kDenseBf16Lds, s,
-                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
-                           static_cast<const float*>(m->d_pack[4]), hid);
-    } else {
-        MDC_LAUNCH_D1(0);
+    if (abl >= 1 && abl <= 3) {
+        switch (abl) { case 1: MDC_LAUNCH_D1(1); break; case 2: MDC_LAUNCH_D1(2); break; default: MDC_LAUNCH_D1(3); }
+        MDC_HIP(hipGetLastError());
+        return MDC_OK;
     }
 #endif
+#ifdef MDC_ALTERNATES
+    if (m->alt & kAltDense1Simple) {      // one barrier per K-tile (bit-identical results; the phased kernel's race screen)
+        MDC_LAUNCH_D1(0);
+        MDC_HIP(hipGetLastError());
+        return MDC_OK;
+    }
+    if (m->alt & kAltSeparateHead) fuse_head = false;
+#endif
 #undef MDC_LAUNCH_D1
+    if (fuse_head && (probs || labels)) {
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseHeadLds));
+        hipLaunchKernelGGL((vt_dense1_bf16_phased_kernel<0, true>), grid, dim3(512), kDenseHeadLds, s, f, (long)n, w1t, c1, hid,
+                           static_cast<const float*>(m->d_pack[5]), (int)m->topo.classes, probs, labels);
+        if (fused) *fused = true;
+    } else {
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
+        hipLaunchKernelGGL((vt_dense1_bf16_phased_kernel<0, false>), grid, dim3(512), kDenseBf16Lds, s, f, (long)n, w1t, c1, hid);
+    }
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

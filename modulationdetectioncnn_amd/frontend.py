@@ -40,6 +40,8 @@ def frames_from_iq_u8(iq, scale: float = DEFAULT_SCALE, device=None, hop: int = 
     if not t.is_cuda:
         t = t.to(device if device is not None else "cuda:0")
     t = t.contiguous().view(-1)
+    if t.data_ptr() % 2:
+        t = t.clone()       # a view starting at an odd byte of a larger buffer: the ABI wants whole (I,Q) pairs
     n = window_count(t.numel(), hop)
     x = torch.empty((n, 2, 128), dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):

@@ -46,13 +46,20 @@ def _torch():
 class VTCNN2:
     """A VT-CNN2-family classifier bound to one MI355X."""
 
+    # scratch buffers kept alive at once (one per stream that forwards concurrently; least recently used goes first)
+    MAX_WORKSPACES = 4
+
     def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
-                 fp8_input_absmax: Optional[float] = None):
+                 fp8_input_absmax: Optional[float] = None, keras_conv_order: bool = False, _lib_variant: str = "product"):
         """dtype "f32" | "bf16" (vtcnn2, deployed) | "f16" (deployed) | "fp8" (vtcnn2, deployed).  fp8_input_absmax: the largest
-        |I/Q sample| the fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs saturate."""
+        |I/Q sample| the fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs saturate.
+        keras_conv_order (MDC_OPT_KERAS_CONV_ORDER): the 10-filter deployed net at f32 keeps Keras' two-fma conv instead of
+        the re-associated pivot form (same function within 2e-6; 7-9 % slower).  _lib_variant: tests only (the alternates build)."""
         self.topology = topology
         self.dtype = dtype
         self.fp8_input_absmax = fp8_input_absmax
+        self.keras_conv_order = bool(keras_conv_order)
+        self._lib_variant = _lib_variant
         if dtype not in _DTYPE:
             raise ValueError(f"dtype must be one of {sorted(_DTYPE)}")
         # the device is resolved ONCE (None = the device current at construction): the engine handle, the workspace
@@ -62,11 +69,11 @@ class VTCNN2:
         self._handle: Optional[C.c_void_p] = None
         self._ws = {}
         self._ws_need = {}      # frames per launch -> mdc_workspace_bytes (a property of the finalized model)
-        # frames per mdc_forward call when the caller gives no batch_size.  VT-CNN2: the workspace holds a call's features
-        # (21 KB/frame in the 16-bit modes): 65,536 frames per call in f32, 2^20 in bf16 / fp8 -- one launch of each kernel for
-        # the headline batch (23 GB of workspace, of 288; +1.5 % over sixteen 65,536-frame launches: each conv launch
-        # reloads its 245 KB of weight fragments per work-group, each dense1 launch has a tail)
-        self.default_chunk = (1 << 20 if dtype in ("bf16", "fp8") else 1 << 16) if topology.kind == "vtcnn2" else 1 << 22
+        # frames per mdc_forward call when the caller gives no batch_size.  VT-CNN2: the workspace holds one call's features
+        # (21.6 KB/frame in the 16-bit modes, 42 KB at f32): 65,536 frames per call = 1.45 GB (f32: 2.8 GB) per stream, and
+        # every launch still fills the chip 16 times over.  A caller with HBM to spare passes batch_size=1 << 20 (23 GB of
+        # workspace, +1.5 %: one launch of each kernel instead of sixteen) -- bench.py's headline does, and says so.
+        self.default_chunk = 1 << 16 if topology.kind == "vtcnn2" else 1 << 22
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -168,6 +175,12 @@ class VTCNN2:
         return [(k.copy(), b.copy()) for k, b in self._weights]
 
     # ------------------------------------------------------------------ engine
+    def _lib(self):
+        return _cabi.lib(self._lib_variant)
+
+    def _check(self, rc: int) -> int:
+        return _cabi.check(rc, self._lib_variant)
+
     @staticmethod
     def _resolve_device(device) -> Optional[int]:
         """int | "cuda:N" | torch.device | None.  None is resolved when a GPU is present (at construction, else at
@@ -196,18 +209,19 @@ class VTCNN2:
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("no ROCm device visible: the MI355X path has no CPU fallback")
-        L = _cabi.lib()
+        L = self._lib()
         t = self.topology
-        topo = _cabi.MdcTopology(_KIND[t.kind], t.filters, t.hidden, t.classes, (C.c_int32 * 4)(0, 0, 0, 0))
+        opts = _cabi.OPT_KERAS_CONV_ORDER if self.keras_conv_order else 0
+        topo = _cabi.MdcTopology(_KIND[t.kind], t.filters, t.hidden, t.classes, (C.c_int32 * 4)(opts, 0, 0, 0))
         h = C.c_void_p()
-        _cabi.check(L.mdc_create(C.byref(topo), self.device_index, C.byref(h)))
+        self._check(L.mdc_create(C.byref(topo), self.device_index, C.byref(h)))
         try:
             for i, (k, b) in enumerate(self._weights):
-                _cabi.check(L.mdc_set_weights(h, i, k.ctypes.data_as(C.POINTER(C.c_float)), k.size,
+                self._check(L.mdc_set_weights(h, i, k.ctypes.data_as(C.POINTER(C.c_float)), k.size,
                                               b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
             if self.fp8_input_absmax is not None:
-                _cabi.check(L.mdc_set_fp8_input_absmax(h, float(self.fp8_input_absmax)))
-            _cabi.check(L.mdc_finalize(h, _DTYPE[self.dtype]))
+                self._check(L.mdc_set_fp8_input_absmax(h, float(self.fp8_input_absmax)))
+            self._check(L.mdc_finalize(h, _DTYPE[self.dtype]))
         except Exception:
             L.mdc_destroy(h)
             raise
@@ -216,7 +230,7 @@ class VTCNN2:
 
     def _release(self) -> None:
         if self._handle is not None:
-            _cabi.lib().mdc_destroy(self._handle)
+            self._lib().mdc_destroy(self._handle)
             self._handle = None
         self._ws = {}
         self._ws_need = {}
@@ -230,7 +244,7 @@ class VTCNN2:
     def _workspace(self, n: int, stream_key: Optional[int] = None):
         need = self._ws_need.get(n)
         if need is None:
-            need = self._ws_need[n] = int(_cabi.lib().mdc_workspace_bytes(self._engine(), n))
+            need = self._ws_need[n] = int(self._lib().mdc_workspace_bytes(self._engine(), n))
         if need == 0:
             return None, 0
         torch = _torch()
@@ -238,9 +252,15 @@ class VTCNN2:
         # it (the C ABI leaves the workspace to the caller for exactly this reason); allocated under the stream
         # that uses it, so torch's caching allocator orders any reuse after the launches already queued there
         key = stream_key if stream_key is not None else torch.cuda.current_stream(torch.device("cuda", self.device_index)).cuda_stream
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < need:
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=f"cuda:{self.device_index}")
+            ws = torch.empty(need, dtype=torch.uint8, device=f"cuda:{self.device_index}")
+        self._ws[key] = ws                      # (dict order = recency: re-inserted at the end)
+        while len(self._ws) > self.MAX_WORKSPACES:
+            # streams that are gone (worker threads' streams, a finished MultiStreamPredictor) do not pin HBM for ever:
+            # the least recently used buffer goes back to torch's caching allocator, which keeps a block freed while
+            # its stream still has work queued away from other streams until that work is done
+            self._ws.pop(next(iter(self._ws)))
         return ws, need
 
     # ------------------------------------------------------------------ inference
@@ -268,7 +288,7 @@ class VTCNN2:
         n = x.shape[0]
         Cn = self.topology.classes
         h = self._engine()
-        L = _cabi.lib()
+        L = self._lib()
         dev = x.device
         if probs is None:
             probs = torch.empty((n, Cn), dtype=torch.float32, device=dev)
@@ -285,7 +305,7 @@ class VTCNN2:
         tap_row = int(np.prod(self.tap_shape(tap))) if tap is not None else 0
         for s in range(0, n, chunk):
             m = min(chunk, n - s)
-            _cabi.check(L.mdc_forward(
+            self._check(L.mdc_forward(
                 h, x.data_ptr() + s * 1024, m,
                 probs.data_ptr() + s * Cn * 4, labels.data_ptr() + s * 4,
                 (tap_out.data_ptr() + s * tap_row * 4) if tap is not None else None, _TAP[tap],
@@ -315,7 +335,7 @@ class VTCNN2:
         else:
             probs = np.empty((n, Cn), np.float32) if want_probs else None
             labels = np.empty((n,), np.int32) if want_labels else None
-        _cabi.check(_cabi.lib().mdc_predict_host(self._engine(), a.ctypes.data, n,
+        self._check(self._lib().mdc_predict_host(self._engine(), a.ctypes.data, n,
                                                  probs.ctypes.data if probs is not None else None,
                                                  labels.ctypes.data if labels is not None else None, self._host_chunk(batch_size)))
         return probs, labels
@@ -369,10 +389,11 @@ class VTCNN2:
         counts = torch.zeros((Cn, Cn), dtype=torch.int64, device=dev)
         bad = torch.zeros((1,), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
-            _cabi.check(_cabi.lib().mdc_confusion(truth.data_ptr(), pred.data_ptr(), pred.numel(), Cn, counts.data_ptr(),
+            self._check(self._lib().mdc_confusion(truth.data_ptr(), pred.data_ptr(), pred.numel(), Cn, counts.data_ptr(),
                                                   bad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
-        if int(bad.item()):
-            raise ValueError(f"{int(bad.item())} labels lie outside [0, {Cn})")
+        nbad = int(bad.item())                  # the one synchronising read
+        if nbad:
+            raise ValueError(f"{nbad} labels lie outside [0, {Cn})")
         return counts
 
     def confusion(self, X, labels_true, batch_size: Optional[int] = None, normalize: bool = True) -> np.ndarray:
@@ -413,7 +434,7 @@ class VTCNN2:
         counts = torch.zeros((S, Cn, Cn), dtype=torch.int64, device=dev)
         bad = torch.zeros((1,), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
-            _cabi.check(_cabi.lib().mdc_confusion_binned(truth.data_ptr(), pred.data_ptr(), bins.data_ptr(), pred.numel(), Cn, S,
+            self._check(self._lib().mdc_confusion_binned(truth.data_ptr(), pred.data_ptr(), bins.data_ptr(), pred.numel(), Cn, S,
                                                          counts.data_ptr(), bad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         host = torch.cat([counts.view(-1), bad]).cpu().numpy()      # the one synchronising copy
         if int(host[-1]):
@@ -437,11 +458,24 @@ class VTCNN2:
 
     @staticmethod
     def load_results(path: str) -> Tuple[str, float, Dict]:
-        """Read back a file written by save_results (a file this package wrote itself; never one shipped by others)."""
+        """Read back a results file: the (tag, dropout, {snr: accuracy}) tuple of save_results holds only str / float /
+        int / dict / tuple, which unpickle without a single global -- so the loader REFUSES every global (class or
+        function reference): a file that names one (any third party's pickle, a hostile one) raises instead of running
+        code from it."""
         import pickle
+
+        class _NoGlobals(pickle.Unpickler):
+            def find_class(self, module, name):
+                raise pickle.UnpicklingError(f"results files hold plain numbers and strings only; refusing {module}.{name}")
+
         with open(path, "rb") as fd:
-            tag, dr, acc = pickle.load(fd)
-        return tag, dr, acc
+            obj = _NoGlobals(fd).load()
+        if not (isinstance(obj, tuple) and len(obj) == 3 and isinstance(obj[0], str) and isinstance(obj[1], (int, float))
+                and isinstance(obj[2], dict)
+                and all(isinstance(k, (int, float)) and isinstance(v, (int, float)) for k, v in obj[2].items())):
+            raise ValueError(f"{path} is not a (tag, dropout, {{snr: accuracy}}) results file")
+        tag, dr, acc = obj
+        return tag, float(dr), acc
 
     # ------------------------------------------------------------------ FPGA arithmetic (SURVEY.md 8(f) item 1)
     def predict_q612(self, X, as_float: bool = True):
@@ -461,7 +495,7 @@ class VTCNN2:
         n, Cn = t.shape[0], self.topology.classes
         dense = torch.empty((n, Cn), dtype=torch.int32, device=t.device)
         labels = torch.empty((n,), dtype=torch.int32, device=t.device)
-        _cabi.check(_cabi.lib().mdc_forward_q612(self._engine(), t.data_ptr() if n else None, int(is_q), n, dense.data_ptr(),
+        self._check(self._lib().mdc_forward_q612(self._engine(), t.data_ptr() if n else None, int(is_q), n, dense.data_ptr(),
                                                  labels.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream))
         out = dense.to(torch.float32) / 4096.0 if as_float else dense
         return (out.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (out, labels)
@@ -484,7 +518,7 @@ class VTCNN2:
             b = np.ascontiguousarray(np.asarray(iq, dtype=np.uint8)).reshape(-1)
             n, Cn = window_count(b.size, hop), self.topology.classes
             probs, labels = np.empty((n, Cn), np.float32), np.empty((n,), np.int32)
-            _cabi.check(_cabi.lib().mdc_predict_host_iq_u8(self._engine(), b.ctypes.data, n, int(hop), scale, probs.ctypes.data,
+            self._check(self._lib().mdc_predict_host_iq_u8(self._engine(), b.ctypes.data, n, int(hop), scale, probs.ctypes.data,
                                                            labels.ctypes.data, self._host_chunk(batch_size)))
             return probs, labels
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(iq, dtype=np.uint8))) if as_numpy else iq
@@ -502,29 +536,29 @@ class VTCNN2:
             x = frames_from_iq_u8(t, scale, hop=hop)
             self.forward_device(x, probs, labels, batch_size=batch_size or None)
         else:
-            L, h = _cabi.lib(), self._engine()
+            L, h = self._lib(), self._engine()
             chunk = max(1, min(int(batch_size) if batch_size else self.default_chunk, n))
             with torch.cuda.device(t.device):
                 stream = torch.cuda.current_stream(t.device).cuda_stream
                 ws, ws_bytes = self._workspace(chunk, stream)
                 for s0 in range(0, n, chunk):
                     m = min(chunk, n - s0)
-                    _cabi.check(L.mdc_forward_iq_u8(h, t.data_ptr() + 2 * hop * s0, m, hop, scale,
+                    self._check(L.mdc_forward_iq_u8(h, t.data_ptr() + 2 * hop * s0, m, hop, scale,
                                                     probs.data_ptr() + s0 * Cn * 4, labels.data_ptr() + s0 * 4,
                                                     ws.data_ptr() if ws is not None else None, ws_bytes, stream))
         return (probs.cpu().numpy(), labels.cpu().numpy()) if as_numpy else (probs, labels)
 
     # ------------------------------------------------------------------ measurement hooks
     def set_profiling(self, on: bool) -> None:
-        _cabi.check(_cabi.lib().mdc_set_profiling(self._engine(), int(on)))
+        self._check(self._lib().mdc_set_profiling(self._engine(), int(on)))
         if on:
-            _cabi.check(_cabi.lib().mdc_profile_reset(self._engine()))
+            self._check(self._lib().mdc_profile_reset(self._engine()))
 
     def read_profile(self) -> Dict[str, Tuple[float, int]]:
-        L, h = _cabi.lib(), self._engine()
+        L, h = self._lib(), self._engine()
         out = {}
         for i in range(L.mdc_profile_slots(h)):
             ms, cnt = C.c_double(), C.c_int64()
-            _cabi.check(L.mdc_profile_read(h, i, C.byref(ms), C.byref(cnt)))
+            self._check(L.mdc_profile_read(h, i, C.byref(ms), C.byref(cnt)))
             out[L.mdc_profile_name(h, i).decode()] = (ms.value, cnt.value)
         return out

@@ -42,6 +42,33 @@ def world() -> Tuple[int, int]:
     return (d.get_rank(), d.get_world_size()) if d else (0, 1)
 
 
+def collective_device(d=None, device=None):
+    """The device a tensor must live on to enter a collective of the default process group: RCCL ("nccl") only takes
+    tensors in HBM -- this process's current GPU (bench.py / the launcher select it per rank) unless the caller names
+    one; gloo (the CPU tests) takes host tensors.  A CPU tensor handed to an nccl collective raises."""
+    import torch
+    d = d or _dist()
+    backend = str(d.get_backend()).lower() if d else "gloo"
+    if "nccl" not in backend or "gloo" in backend or "mpi" in backend:      # a host backend is there ("gloo", "cpu:gloo,cuda:nccl")
+        return torch.device("cpu")
+    if device is not None and torch.device(device).type == "cuda":
+        return torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def all_reduce_array(a: np.ndarray, op: str = "sum", device=None) -> np.ndarray:
+    """Element-wise reduction of a small host array over the ranks (off the data path: elapsed times, C x C counts).
+    The array travels through a tensor on `collective_device()`, so the same call is valid under RCCL and gloo."""
+    d = _dist()
+    a = np.ascontiguousarray(a)
+    if not d:
+        return a
+    import torch
+    t = torch.from_numpy(a.copy()).to(collective_device(d, device))
+    d.all_reduce(t, op={"sum": d.ReduceOp.SUM, "max": d.ReduceOp.MAX}[op])
+    return t.cpu().numpy()
+
+
 def timed_region(step: Callable[[], None], steps: int, warmup: int, sync: Optional[Callable[[], None]] = None,
                  device=None) -> float:
     """bench.py's timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by
@@ -62,10 +89,7 @@ def timed_region(step: Callable[[], None], steps: int, warmup: int, sync: Option
         d.barrier()
     el = time.perf_counter() - t0
     if d:
-        import torch
-        t = torch.tensor([el], dtype=torch.float64, device=device if device is not None else "cpu")
-        d.all_reduce(t, op=d.ReduceOp.MAX)
-        el = float(t.item())
+        el = float(all_reduce_array(np.array([el], np.float64), "max", device)[0])
     return el
 
 
@@ -107,6 +131,8 @@ class ShardedPredictor:
             return (p, l) if gather else (bounds, p, l)
         d = _dist()
         parts: List[object] = [None] * self.world
+        # (an object collective pickles on the host and, under RCCL, moves the bytes through the CURRENT GPU's memory:
+        # torch does that staging itself, nothing here hands a host tensor to the backend)
         d.all_gather_object(parts, (bounds, p, l))
         parts.sort(key=lambda t: t[0][0])
         assert [b for b, _, _ in parts] == shard_bounds(len(X), self.world)
@@ -215,10 +241,6 @@ def confusion_counts(labels_true: np.ndarray, labels_pred: np.ndarray, classes: 
     summed over ranks (C*C integers: the only cross-GPU reduction the evaluation path ever needs)."""
     conf = np.zeros((classes, classes), np.int64)
     np.add.at(conf, (np.asarray(labels_true), np.asarray(labels_pred)), 1)
-    d = _dist()
-    if reduce and d:
-        import torch
-        t = torch.from_numpy(conf)
-        d.all_reduce(t, op=d.ReduceOp.SUM)
-        conf = t.numpy()
+    if reduce:
+        conf = all_reduce_array(conf, "sum")      # through HBM under RCCL, through host memory under gloo
     return conf

@@ -24,8 +24,11 @@ def _frames():
     return raw.astype(np.float32) / np.float32(4096), meta
 
 
-def _model(name):
-    return VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"))
+_VARIANT = "product"      # the f32_mfma fixture switches to the alternates test build (libmdc_alt.so)
+
+
+def _model(name, **kw):
+    return VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), _lib_variant=_VARIANT, **kw)
 
 
 def _check_labels(lab, ref64, tol=1e-5):
@@ -287,12 +290,24 @@ def test_16bit_modes_keep_an_out_of_range_frame_to_itself(dtype):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# The f32 variant with Dense(3) on the f32 matrix pipe (csrc/deployed_f32m.hip, MDC_DEP_F32_MFMA=1): same bar as the
-# production f32 kernel.  It is kept as the measured answer to "can the dense layer leave the VALU at f32?" (DESIGN.md
-# section 4.1c): correct to the same tolerances, slower.
+# The f32 variant with Dense(3) on the f32 matrix pipe (csrc/deployed_f32m.hip): same bar as the production f32 kernel.
+# It is kept as the measured answer to "can the dense layer leave the VALU at f32?" (DESIGN.md section 4.1c): correct to
+# the same tolerances, slower -- so it lives in the alternates test build only (libmdc_alt.so, -DMDC_ALTERNATES), where
+# mdc_create reads MDC_DEP_F32_MFMA=1 once per model.
 @pytest.fixture
 def f32_mfma(monkeypatch):
-    monkeypatch.setenv("MDC_DEP_F32_MFMA", "1")       # read by libmdc.so on every call
+    import sys
+    monkeypatch.setenv("MDC_DEP_F32_MFMA", "1")       # read by libmdc_alt.so when a model is created
+    monkeypatch.setattr(sys.modules[__name__], "_VARIANT", "alternates")
+
+
+def test_the_alternates_build_runs_the_product_kernels_unless_told_otherwise():
+    """libmdc_alt.so without any of its environment variables is the product: bit-identical results."""
+    x = synthetic_frames(1000, seed=4)
+    for name in ("3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"):
+        a = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz")).predict(x)
+        b = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), _lib_variant="alternates").predict(x)
+        np.testing.assert_array_equal(a, b)
 
 
 def test_f32_mfma_variant_keras_known_answer_and_bundled_frames(f32_mfma):
@@ -412,17 +427,17 @@ def test_fp8_mode_of_the_deployed_nets(name):
 # ---- F = 10, f32: the pivot form of the conv (one fma + one med3 per output; deployed.hip) and the plain form behind it
 @pytest.mark.parametrize("n", [1, 63, 65, 70001])
 def test_pivot_and_plain_conv_forms_both_meet_the_oracle(monkeypatch, n):
-    """The bundled 10-filter net takes the pivot form (every K1 != 0); MDC_DEP_PIVOT=0 selects the plain two-fma form.
-    Both are held to the f64 oracle at the f32 bar, frames and raw bytes, and they agree with each other."""
+    """The bundled 10-filter net takes the pivot form (every K1 != 0); keras_conv_order=True (MDC_OPT_KERAS_CONV_ORDER, fixed
+    when the model is created) keeps the plain two-fma form.  Both are held to the f64 oracle at the f32 bar, and they
+    agree with each other."""
     name = "convmodrecnets_CNN2_0.5"
     x = synthetic_frames(n, seed=77) * np.float32(2.5)
     w = [a for p in load_deployed_npz(name) for a in p]
     ref = O.forward_deployed(x, *w, dtype=np.float64)
     scale = max(1.0, float(np.abs(ref["dense"]).max()))
-    m = _model(name)
     got = {}
     for form in ("1", "0"):
-        monkeypatch.setenv("MDC_DEP_PIVOT", form)
+        m = _model(name, keras_conv_order=(form == "0"))
         d, p, l = m.predict(x, tap="dense"), m.predict(x), m.predict_classes(x)
         np.testing.assert_allclose(d, ref["dense"], rtol=0, atol=2e-6 * scale)
         np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
@@ -434,7 +449,7 @@ def test_pivot_and_plain_conv_forms_both_meet_the_oracle(monkeypatch, n):
 
 def test_degenerate_conv_taps_fall_back_to_the_plain_form(monkeypatch):
     """A filter whose second tap is zero (or whose tap ratio is huge) has no pivot: the library must run the plain form
-    -- the results are then bit-identical with and without MDC_DEP_PIVOT=0 -- and still meet the oracle."""
+    -- the results are then bit-identical with and without keras_conv_order -- and still meet the oracle."""
     topo = Topology.deployed(10, 3)
     (ck, cb), (dk, db) = synthetic_weights(topo, seed=5, bias_scale=0.05)
     ck = np.array(ck, np.float32)
@@ -444,8 +459,7 @@ def test_degenerate_conv_taps_fall_back_to_the_plain_form(monkeypatch):
     ref = O.forward_deployed(x, ck, cb, dk, db, dtype=np.float64)
     outs = []
     for form in ("1", "0"):
-        monkeypatch.setenv("MDC_DEP_PIVOT", form)
-        m = VTCNN2(topo)
+        m = VTCNN2(topo, keras_conv_order=(form == "0"))
         m.set_weights([(ck, cb), (dk, db)])
         p = m.predict(x)
         np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
@@ -457,8 +471,7 @@ def test_degenerate_conv_taps_fall_back_to_the_plain_form(monkeypatch):
     ref2 = O.forward_deployed(x, ck2, cb2, dk2, db2, dtype=np.float64)
     outs = []
     for form in ("1", "0"):
-        monkeypatch.setenv("MDC_DEP_PIVOT", form)
-        m = VTCNN2(topo)
+        m = VTCNN2(topo, keras_conv_order=(form == "0"))
         m.set_weights([(ck2, cb2), (dk2, db2)])
         d = m.predict(x, tap="dense")
         np.testing.assert_allclose(d, ref2["dense"], rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref2["dense"]).max())))

@@ -188,3 +188,33 @@ def test_sv_rom_equals_latest_weights(reference_dir):
     sv_dense = [t.rows for t in sv.tables if len(t) == 387]
     txt_dense = [t.rows for t in txt.tables if len(t) == 387]
     assert len(sv_dense) == 6 and sv_dense == txt_dense
+
+
+def test_results_file_loader_runs_no_code_from_the_file(tmp_path):
+    """load_results used plain pickle.load.  The results tuple of cnn.py:262-264 needs no global at all, so the
+    loader refuses every one: a pickle that names a callable (the classic os.system payload, or just a numpy scalar from
+    somebody else's writer) raises instead of importing anything; a well-formed file still round-trips."""
+    import pickle
+    from modulationdetectioncnn_amd import VTCNN2
+    good = tmp_path / "results_cnn2_d0.5.dat"
+    VTCNN2.save_results(str(good), {-20: 0.25, 0: 0.5, 18: 0.875})
+    assert VTCNN2.load_results(str(good)) == ("CNN2", 0.5, {-20: 0.25, 0: 0.5, 18: 0.875})
+    marker = tmp_path / "pwned"
+
+    class Payload:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {marker}",))
+    evil = tmp_path / "evil.dat"
+    evil.write_bytes(pickle.dumps(("CNN2", 0.5, {0: Payload()}), protocol=2))
+    with pytest.raises(pickle.UnpicklingError, match="refusing"):
+        VTCNN2.load_results(str(evil))
+    assert not marker.exists()
+    npscalar = tmp_path / "np.dat"
+    npscalar.write_bytes(pickle.dumps(("CNN2", 0.5, {0: np.float64(0.5)}), protocol=2))      # needs numpy globals: refused too
+    with pytest.raises(pickle.UnpicklingError):
+        VTCNN2.load_results(str(npscalar))
+    shape = tmp_path / "shape.dat"
+    shape.write_bytes(pickle.dumps(["not", "a", "results", "tuple"], protocol=2))
+    with pytest.raises(ValueError, match="results file"):
+        VTCNN2.load_results(str(shape))

@@ -79,14 +79,14 @@ def test_fullsize_properties(kind, dtype, n, classes):
     xs = x[sub].cpu().numpy()
     okind = "deployed" if kind.startswith("deployed") else kind
     ref = O.forward(okind, xs, w, dtype=np.float64)
-    tol = {"f32": 2e-5, "bf16": 2e-2, "f16": 2e-2, "fp8": 8e-2}[dtype]
+    tol = {"f32": 2e-5, "bf16": 8e-3, "f16": 8e-3, "fp8": 5e-2}[dtype]      # tests/test_vtcnn2_gpu.py: ~2x the measured maxima
     got = p[sub].cpu().numpy()
     if kind.startswith("deployed") and dtype == "fp8":
         bound = 6e-2        # e4m3 operands (tests/test_deployed_gpu.py::test_fp8_mode_of_the_deployed_nets)
     elif kind.startswith("deployed") and dtype != "f32":
         bound = 1e-2        # the 16-bit deployed modes' bar (tests/test_deployed_gpu.py): probabilities within 1e-2
     else:
-        bound = max(2e-6, 2 * tol * np.abs(ref.get("logits", ref.get("dense"))).max())
+        bound = max(2e-6, (2 if dtype == "f32" else 0.5) * tol * np.abs(ref.get("logits", ref.get("dense"))).max())      # reduced modes: half the logit bar
     assert np.abs(got - ref["probs"]).max() <= bound
 
 
@@ -125,9 +125,11 @@ def test_nonfinite_frames_stay_isolated(kind, dtype, n, classes):
 
 
 def test_dense1_kernels_agree_bit_for_bit():
-    """The phased dense1 GEMM (counted vmcnt waits, staggered wave rows) must equal the one-barrier-per-K-tile kernel
-    bit for bit, run after run: a hole in its LDS-DMA ordering shows up as a mismatch that comes and goes.
-    tools/ab_dense1.py runs both (MDC_DENSE1_PHASED=0/1) in child processes on 2^18 frames, four times each."""
+    """The phased dense1 GEMM (counted vmcnt waits, staggered wave rows; the head fused into its epilogue) must equal the
+    one-barrier-per-K-tile kernel and the head-as-its-own-launch form bit for bit -- hidden layer, probabilities and
+    labels --, run after run: a hole in its LDS-DMA ordering or in the epilogue's reuse of the staging buffers shows up
+    as a mismatch that comes and goes.  tools/ab_dense1.py runs the product library and the alternates test build
+    (libmdc_alt.so: MDC_D1_FUSED_HEAD=0, MDC_DENSE1_PHASED=0) in child processes on 2^18 frames, four times each."""
     import os
     import subprocess
     import sys

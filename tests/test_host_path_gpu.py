@@ -118,6 +118,11 @@ def test_host_path_errors():
     assert L.mdc_predict_host(m._engine(), out.ctypes.data, 4, None, None, -5) == -22 and b"chunk" in L.mdc_last_error()
     assert L.mdc_predict_host_iq_u8(m._engine(), out.ctypes.data, 4, 0, 1.0, None, None, 0) == -22 and b"hop" in L.mdc_last_error()
     assert L.mdc_predict_host(m._engine(), None, 0, None, None, 0) == 0
+    # a DEVICE pointer must not reach the staging threads' memcpy
+    xd = synthetic_frames(64, seed=1, device="cuda")
+    assert L.mdc_predict_host(m._engine(), xd.data_ptr(), 64, out.ctypes.data, None, 0) == -22 and b"device memory" in L.mdc_last_error()
+    iqd = torch.zeros(4 * 256, dtype=torch.uint8, device="cuda")
+    assert L.mdc_predict_host_iq_u8(m._engine(), iqd.data_ptr(), 4, 128, 1.0, out.ctypes.data, None, 0) == -22 and b"device memory" in L.mdc_last_error()
     cn = VTCNN2.synthetic("cnnpy")
     assert L.mdc_predict_host_iq_u8(cn._engine(), out.ctypes.data, 1, 128, 1.0, None, None, 0) == -95
     x = synthetic_frames(100, seed=1)

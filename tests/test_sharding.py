@@ -226,10 +226,13 @@ def _bench_worker(rank, world, port, out_dir):
         topology = Topology.vtcnn2(11)
         dtype = "bf16"
 
-    def run_workload(name, device, steps, warmup, dist=None):
+    calls = []
+
+    def run_workload(name, device, steps, warmup, dist=None, frames=None):
         assert dist is not None and dist.get_world_size() == world and device == rank
+        calls.append((name, frames))
         el = timed_region(lambda: time.sleep(0.02 * (rank + 1)), steps, warmup)      # rank 1 is twice as slow
-        return _Stub(), None, None, None, n, el
+        return _Stub(), None, None, None, (n if frames is None else frames), el
 
     bench.run_workload = run_workload
     bench.select_device = lambda d: None
@@ -239,6 +242,8 @@ def _bench_worker(rank, world, port, out_dir):
         bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "1", "--no-extras", "--no-cpu-baseline"])
     with open(os.path.join(out_dir, f"out{rank}.txt"), "w") as f:
         f.write(buf.getvalue())
+    # every rank ran the headline and then the two other readings, each on ITS shard (strong: 2^20 / world frames)
+    assert calls == [("vtcnn2-c11-bf16-n2^20", None), ("vtcnn2-c11-bf16-n2^20", (1 << 20) // world), ("vtcnn2-c11-bf16-n2^21", 1 << 21)], calls
 
 
 def test_bench_main_under_gloo_world2(tmp_path):
@@ -253,4 +258,44 @@ def test_bench_main_under_gloo_world2(tmp_path):
     assert j["config"]["frames_per_gpu"] == 4096 and j["config"]["global_batch"] == 8192
     assert j["ms_per_step"] >= 40 * 0.9                               # MAX over ranks: the slow rank's 40 ms per step
     assert abs(j["value"] - 8192 * 4 / (j["ms_per_step"] * 4e-3)) / j["value"] < 1e-6     # whole-job frames / MAX time
-    assert j["metric"].endswith("batch=4096)") and "cpu_baseline" not in j and "extra" not in j
+    assert j["metric"].endswith("batch=4096)") and "cpu_baseline" not in j
+    # the other two readings of "batch=2^20 at 1/2/4/8 MI355X" and of configs[3], as extra legs with their batch stated
+    strong, shard = j["extra"]
+    assert strong["scaling"] == "strong" and strong["global_batch"] == 1 << 20 and strong["frames_per_gpu"] == 1 << 19 and strong["n_gpus"] == 2
+    assert shard["scaling"] == "weak" and shard["frames_per_gpu"] == 1 << 21 and shard["global_batch"] == 1 << 22 and shard["workload"].endswith("n2^21")
+    for leg in (strong, shard):
+        assert abs(leg["value"] - leg["global_batch"] * leg["steps"] / (leg["ms_per_step"] * leg["steps"] * 1e-3)) / leg["value"] < 1e-6
+        assert leg["ms_per_step"] >= 40 * 0.9                         # MAX over ranks here too
+
+
+def test_collective_device_follows_the_backend(monkeypatch):
+    """under RCCL ("nccl") a CPU tensor must never reach a collective; under gloo it must stay on the host."""
+    from modulationdetectioncnn_amd import sharding
+
+    class _D:
+        def __init__(self, b):
+            self.b = b
+
+        def get_backend(self):
+            return self.b
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 3)
+    assert sharding.collective_device(_D("gloo")) == torch.device("cpu")
+    assert sharding.collective_device(_D("cpu:gloo,cuda:nccl")) == torch.device("cpu")      # a host backend is there
+    assert sharding.collective_device(_D("nccl")) == torch.device("cuda", 3)
+    assert sharding.collective_device(_D("nccl"), device="cuda:5") == torch.device("cuda", 5)
+    assert sharding.collective_device(_D("nccl"), device="cpu") == torch.device("cuda", 3)
+
+    # every reduction of the module goes through all_reduce_array, which places its tensor there
+    seen = []
+
+    class _Dist(_D):
+        class ReduceOp:
+            SUM, MAX = "sum", "max"
+
+        def all_reduce(self, t, op):
+            seen.append((t.device.type, op))
+    monkeypatch.setattr(sharding, "_dist", lambda: _Dist("gloo"))
+    monkeypatch.setattr(sharding, "collective_device", lambda d=None, device=None: torch.device("meta"))
+    with pytest.raises(Exception):          # a meta tensor cannot come back to numpy: what matters is where it WENT
+        sharding.confusion_counts(np.array([0, 1]), np.array([1, 1]), 3)
+    assert seen == [("meta", "sum")]

@@ -5,9 +5,12 @@ weights are bundled): parity is against this repo's f64 oracle ("parity unpinned
 Tolerances (relative to the largest |logit| of the batch, since the net is positively
 homogeneous in its input scale):
   f32 path : 2e-5   (exact-f32 MFMA fma chains, K up to 10560)
-  bf16 path: 2e-2   (bf16 operands, f32 accumulation)
-  fp8 path : 8e-2   (conv2 on e4m3 operands, measured 3-4e-2; its activations are scaled for a stated input range)
-Labels: bit-exact wherever the oracle's top-2 logit margin exceeds 4x the tolerance."""
+  bf16 path: 8e-3   (bf16 operands, f32 accumulation; the largest error over this file's scenarios is 3.8e-3 on the logits,
+                     4.0e-3 on the features, 8e-4 on the probabilities: tools/measure_bars.py -> profiles/r03_measured_bars.json)
+  fp8 path : 5e-2   (conv2 on e4m3 operands, measured 3.7e-2 / 3.8e-2 / 1.0e-2; activations scaled for a stated input range)
+i.e. about twice (fp8: 1.3 x) what is measured -- round 2's 2e-2 / 8e-2 would have passed a kernel three times as wrong.
+Probabilities: half the logit bar (softmax contracts).  Labels: bit-exact wherever the oracle's top-2 logit margin
+exceeds 4x the tolerance; every frame counts in tests/test_label_agreement_gpu.py."""
 import numpy as np
 import pytest
 import torch
@@ -17,7 +20,7 @@ from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32": 2e-5, "bf16": 2e-2, "fp8": 8e-2}
+TOL = {"f32": 2e-5, "bf16": 8e-3, "fp8": 5e-2}
 _cache = {}
 
 
@@ -43,7 +46,7 @@ def _check(m, w, x, dtype, batch_size=None):
     lg = m.predict(x, tap="dense", batch_size=batch_size)
     assert np.abs(lg - ref["logits"]).max() <= tol * scale, (np.abs(lg - ref["logits"]).max() / scale)
     p = m.predict(x, batch_size=batch_size)
-    assert np.abs(p - ref["probs"]).max() <= max(2e-6, 2 * tol * scale)
+    assert np.abs(p - ref["probs"]).max() <= max(2e-6, (2 if dtype == "f32" else 0.5) * tol * scale)
     np.testing.assert_allclose(p.sum(axis=1), 1.0, atol=1e-5)
     lab = m.predict_classes(x, batch_size=batch_size)
     srt = np.sort(ref["logits"], axis=1)
@@ -191,3 +194,60 @@ def test_small_batch_forms_are_bit_identical_to_the_batch_kernels(dtype):
     # a window taken from the middle of the batch, alone
     one = x[4321:4322].contiguous()
     assert torch.equal(m.forward_device(one)[0], big_p[4321:4322])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+@pytest.mark.parametrize("classes", [3, 11, 16])
+def test_head_fused_into_dense1_gives_the_bits_of_the_separate_launch(dtype, classes):
+    """Round 3: above 2,048 frames the 16-bit modes run dense2 + softmax + argmax inside the dense1 GEMM's epilogue (no
+    hidden layer in HBM).  A forward that taps the logits takes the unfused path (dense1 writes the hidden layer, the head
+    is its own launch): probabilities and labels must be the same BITS -- ragged sizes around the 256-row tile included --
+    and so must the small-batch forms' (the first 2,048 frames of the same batch)."""
+    m, _ = _model(classes, dtype, seed=5, bias_scale=0.05)
+    x = synthetic_frames(2 * 4096 + 17, seed=31, device="cuda")
+    for n in (2049, 2304, 4096, 4097, 2 * 4096 + 17):
+        xn = x[:n].contiguous()
+        p_f, l_f, _ = m.forward_device(xn)
+        p_s, l_s, logits = m.forward_device(xn, tap="dense")
+        assert torch.equal(p_f, p_s) and torch.equal(l_f, l_s), (n, classes)
+        assert logits.shape == (n, classes)
+        hid = m.predict(xn, tap="hidden")
+        assert hid.shape == (n, 256) and bool(torch.isfinite(hid).all())
+    small = m.forward_device(x[:2048].contiguous())
+    big = m.forward_device(x[:4096].contiguous())
+    assert torch.equal(small[0], big[0][:2048]) and torch.equal(small[1], big[1][:2048])
+    # only probabilities, only labels
+    xn = x[:3000].contiguous()
+    p_ref, l_ref, _ = m.forward_device(xn)
+    L, h = m._lib(), m._engine()
+    ws, nb = m._workspace(3000)
+    stream = torch.cuda.current_stream().cuda_stream
+    p2 = torch.empty_like(p_ref)
+    l2 = torch.empty_like(l_ref)
+    m._check(L.mdc_forward(h, xn.data_ptr(), 3000, p2.data_ptr(), None, None, 0, ws.data_ptr(), nb, stream))
+    m._check(L.mdc_forward(h, xn.data_ptr(), 3000, None, l2.data_ptr(), None, 0, ws.data_ptr(), nb, stream))
+    assert torch.equal(p2, p_ref) and torch.equal(l2, l_ref)
+
+
+def test_default_workspace_is_bounded_and_old_streams_do_not_pin_hbm():
+    """VERDICT r2 item 6 / ADVICE: predict() on a large batch must not ask for 21 KB x 2^20 of scratch per stream by default
+    -- 65,536-frame calls, < 4 GB at f32, 1.45 GB in the 16-bit modes -- with results identical to the one-launch form a
+    caller opts into with batch_size; at most MAX_WORKSPACES scratch buffers stay alive however many streams came by."""
+    m, _ = _model(11, "bf16")
+    assert m.default_chunk == 1 << 16
+    x = synthetic_frames(3 * 65536 + 5, seed=8, device="cuda")
+    p = m.predict(x)
+    assert sum(t.numel() for t in m._ws.values()) < 2 * 1024 ** 3
+    assert torch.equal(p, m.predict(x, batch_size=x.shape[0]))
+    mf, _ = _model(3, "f32")
+    mf.predict(x[:70000].contiguous())
+    assert sum(t.numel() for t in mf._ws.values()) < 4 * 1024 ** 3
+    m2, _ = _model(11, "bf16")
+    outs = []
+    for _ in range(7):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            outs.append(m2.predict(x[:4096]))
+        st.synchronize()
+    assert len(m2._ws) <= m2.MAX_WORKSPACES == 4
+    assert all(torch.equal(o, outs[0]) for o in outs)

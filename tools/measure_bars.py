@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""ON THE GPU BOX: what the reduced-precision test bars are measured against.  Prints, per mode, the largest error
+(relative to the largest |logit|, the unit of tests/test_vtcnn2_gpu.py's TOL) over the scenarios of the GPU tests, and the
+label agreement with the f32 kernels on N(0, sigma) noise frames and on the signal-shaped frames of tests/signals.py.
+The bars in the tests are about twice these maxima; re-run after touching a kernel's arithmetic."""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames, synthetic_weights
+from oracle import oracle_np as O            # checker
+from signals import modulated_frames
+from conftest import load_deployed_npz
+
+out = {}
+def model(classes, dtype, seed=2016, bias_scale=0.0, absmax=None):
+    topo = Topology.vtcnn2(classes); w = synthetic_weights(topo, seed=seed, bias_scale=bias_scale)
+    m = VTCNN2(topo, dtype=dtype, fp8_input_absmax=absmax if dtype == "fp8" else None); m.set_weights(w); return m, w
+
+xsig, _, _ = modulated_frames(1 << 16, seed=2016)
+for dtype in ("bf16", "fp8"):
+    r = {}
+    worst = 0.0; worst_p = 0.0
+    for classes in (3, 11):
+        m, w = model(classes, dtype)
+        for n in (1, 16, 17, 64, 100, 257):
+            x = synthetic_frames(n, seed=2016)
+            ref = O.forward("vtcnn2", x, w, dtype=np.float64); scale = np.abs(ref["logits"]).max()
+            worst = max(worst, float(np.abs(m.predict(x, tap="dense") - ref["logits"]).max() / scale))
+            worst_p = max(worst_p, float(np.abs(m.predict(x) - ref["probs"]).max() / scale))
+    r["parity: logits / max|logit|"] = worst; r["parity: probs / max|logit|"] = worst_p
+    x = synthetic_frames(96, seed=7, sigma=0.5)
+    m, w = model(11, dtype, seed=5, bias_scale=0.05, absmax=float(np.abs(x).max()))
+    ref = O.forward("vtcnn2", x, w, dtype=np.float64); scale = np.abs(ref["logits"]).max()
+    r["biases + large inputs: logits"] = float(np.abs(m.predict(x, tap="dense") - ref["logits"]).max() / scale)
+    r["biases + large inputs: probs"] = float(np.abs(m.predict(x) - ref["probs"]).max() / scale)
+    x = synthetic_frames(40, seed=3, sigma=0.1)
+    m, w = model(11, dtype, seed=5, bias_scale=0.05, absmax=float(np.abs(x).max()))
+    ref = O.forward("vtcnn2", x, w, dtype=np.float64, taps=True)
+    r["taps: flat / max"] = float(np.abs(m.predict(x, tap="flat") - ref["flat"]).max() / np.abs(ref["flat"]).max())
+    r["taps: hidden / max"] = float(np.abs(m.predict(x, tap="hidden") - ref["dense1"]).max() / np.abs(ref["dense1"]).max())
+    mf, _ = model(11, "f32"); m, w = model(11, dtype)
+    xa = synthetic_frames(8200, seed=21, device="cuda"); ra = mf.predict(xa, tap="dense"); scale = float(ra.abs().max())
+    r["ragged vs f32 kernels: logits"] = max(float((m.predict(xa[:n].contiguous(), tap="dense") - ra[:n]).abs().max()) / scale
+                                             for n in list(range(1, 49)) + [255, 256, 257, 511, 513, 4095, 4096, 4097, 4113, 8200])
+    # signal-shaped frames against the f64 oracle (96 of them) and label agreement with the f32 kernels
+    xs = xsig[:96]; ref = O.forward("vtcnn2", xs, w, dtype=np.float64); scale = np.abs(ref["logits"]).max()
+    r["signal frames: logits"] = float(np.abs(m.predict(xs, tap="dense") - ref["logits"]).max() / scale)
+    r["signal frames: probs"] = float(np.abs(m.predict(xs) - ref["probs"]).max() / scale)
+    for classes in (11, 3):
+        mf, _ = model(classes, "f32"); m, _ = model(classes, dtype)
+        for tag, x in (("noise", synthetic_frames(1 << 16, seed=2016, device="cuda")), ("signal", torch.from_numpy(xsig).cuda())):
+            r[f"label agreement C={classes} {tag}"] = float((mf.predict_classes(x) == m.predict_classes(x)).float().mean())
+    out["vtcnn2 " + dtype] = r
+g = os.path.join(ROOT, "tests", "golden", "weights")
+for name in ("3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5", "5convmodrecnets_CNN2_0.5"):
+    flat = [a for p in load_deployed_npz(name) for a in p]
+    mf = VTCNN2.from_npz(os.path.join(g, name + ".npz"))
+    ref = O.forward_deployed(xsig, *flat, dtype=np.float64)
+    d = ref["dense"]; srt = np.sort(d, axis=1); scale = max(1.0, float(np.abs(d).max()))
+    decided = (srt[:, -1] - srt[:, -2]) > 1e-5 * scale
+    pf = mf.predict(xsig); lf = mf.predict_classes(xsig)
+    r = {"f32 signal: probs err": float(np.abs(pf - ref["probs"]).max()), "f32 signal: decided fraction": float(decided.mean()),
+         "f32 signal: label mismatches among decided": int((lf[decided] != ref["labels"][decided]).sum()),
+         "f32 signal: label mismatches all": int((lf != ref["labels"]).sum()),
+         "f32 signal: dense err / scale": float(np.abs(mf.predict(xsig, tap="dense") - d).max() / scale)}
+    for dtype in ("bf16", "f16", "fp8"):
+        m = VTCNN2.from_npz(os.path.join(g, name + ".npz"), dtype=dtype)
+        r[f"{dtype} signal: probs err vs f64"] = float(np.abs(m.predict(xsig) - ref["probs"]).max())
+        for tag, x in (("noise 5e-3", synthetic_frames(1 << 16, seed=77, sigma=5e-3, device="cuda")),
+                       ("noise 0.1", synthetic_frames(1 << 16, seed=77, sigma=0.1, device="cuda")), ("signal", torch.from_numpy(xsig).cuda())):
+            r[f"{dtype} label agreement {tag}"] = float((mf.predict_classes(x) == m.predict_classes(x)).float().mean())
+    out["deployed " + name] = r
+print(json.dumps(out, indent=1))
