@@ -178,7 +178,20 @@ __device__ __forceinline__ float rows_sum(float m) {       // sum over the four 
 // ONE fma and ONE v_med3_f32(t, lo, hi) per conv output -- (lo, hi) = (-beta, +inf) or (-inf, -beta) -- instead of two
 // fmas and a max; sign(p)*|p| is folded into the dense weights and sum(D' * beta) into the dense bias on the host (in
 // f64, deployed_pack).  The table has the layout of the plain one: head triples (r, lo, hi), bias', weights D'.
-template <int F, int TAP, int ABL = 0, bool TAIL = false, bool U8 = false, bool PIV = false>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
+// RING > 0 (round 3; f32 frames, full blocks): the frames reach the lanes through a per-wave LDS ring of RING groups
+// (4 frames = 4 KiB each) filled by asm-issued LDS-DMA -- one global_load_lds_dwordx4 = one whole frame, 1 KiB contiguous,
+// landing lane-linear, read back by the same lane with one ds_read_b128: the registers hold exactly what the direct
+// load would have put there, the arithmetic below is untouched (T1 stays Keras' order; results bit-identical to RING = 0).
+// The wave's blocks form ONE stream of groups: at group g the wave (a) waits lgkmcnt(0) -- the reads of group g, issued a
+// whole group of arithmetic earlier, are out of their slot --, (b) issues the copies of group g + RING into that slot,
+// (c) waits vmcnt(4 (RING - 1)): group g + 1 has landed (vmcnt retires in order; stores of a finished block sit in the
+// same queue and only make the wait stricter), (d) reads group g + 1 into registers, (e) computes group g.  RING - 1
+// groups stay in flight per wave across group AND block boundaries (the direct-load form drains at every block start);
+// groups past the wave's last one are clamped copies of it, so the count of outstanding copies stays uniform, and the
+// wave drains with vmcnt(0) before it ends (a copy must not land in LDS that already belongs to another work-group).
+// Round 2 tried this ring with the builtin and saw no gain: hipcc put a vmcnt(0) in front of every LDS read (DESIGN.md
+// 4.1b, "the LDS-DMA rings were not rings").
+template <int F, int TAP, int ABL = 0, bool TAIL = false, bool U8 = false, bool PIV = false, int RING = 0>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
 __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restrict__ x, long n,
                                                            const float* __restrict__ wp,
                                                            float* __restrict__ probs, int* __restrict__ labels,
@@ -221,7 +234,39 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
     const long nwaves = (long)gridDim.x * 4;
     const long nblk = TAIL ? 1 : (n >> 6);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (long blk = (long)blockIdx.x * 4 + wv; blk < nblk; blk += nwaves) {
+    static_assert(RING == 0 || (!TAIL && !U8 && RING >= 2), "the ring form serves full blocks of f32 frames");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_mem[];
+    unsigned char* const ring = ring_mem + (RING ? wv * (RING * 4096) : 0);
+    const long blk0 = (long)blockIdx.x * 4 + wv;
+    const long my_groups = (RING && blk0 < nblk) ? ((nblk - blk0 + nwaves - 1) / nwaves) * 16 : 0;      // this wave's stream
+    long gi = 0;                                                                                         // its current group
+    auto ring_issue = [&](long g) {      // the four frames of group g (clamped to the stream's last group) -> slot g % RING
+        const long gc = g < my_groups ? g : my_groups - 1;
+        const float* src = x + (((blk0 + (gc >> 4) * nwaves) << 6) + 4 * (gc & 15)) * (long)kFrameFloats + 4 * lane;
+        unsigned char* slot = ring + (g % RING) * 4096;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(slot + f * 1024);
+            asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(src + f * kFrameFloats), "{m0}"(l) : "memory");
+        }
+    };
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    auto ring_read = [&](long g, f32x4 (&dst)[4]) {
+        const unsigned char* slot = ring + (g % RING) * 4096 + lane * 16;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) dst[f] = *reinterpret_cast<const f32x4*>(slot + f * 1024);
+    };
+    f32x4 ring_cur[4], ring_nx[4];
+    if constexpr (RING > 0) {
+        if (my_groups == 0) return;      // (a wave without a block has issued nothing)
+        for (int g = 0; g < RING; ++g) ring_issue(g);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING - 1)) : "memory");
+        ring_read(0, ring_cur);
+    }
+    using Raw = typename std::conditional<U8, uint2, float4>::type;
+    Raw cur_raw[4], nx[4];
+    bool first_block = true;      // direct-load form: only a wave's first block loads its first group synchronously
+    for (long blk = blk0; blk < nblk; blk += nwaves) {
         const long base = blk << 6;
         float r[kC] = {0.f, 0.f, 0.f};
         // x[0][0] / x[1][0] of every frame go through a 512-byte LDS table (written by lanes 0 and 32 as the
@@ -229,10 +274,8 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
         float eI = 0.f, eQ = 0.f;
         const float4* px = reinterpret_cast<const float4*>(x + base * kFrameFloats) + lane;
         const unsigned char* pb = reinterpret_cast<const unsigned char*>(x) + base * hop2 + lp * 8;
-        using Raw = typename std::conditional<U8, uint2, float4>::type;
-        Raw cur_raw[4], nx[4];
         float4 cur[4];
-        auto load = [&](int j) -> Raw {
+        auto load = [&](long j) -> Raw {
             if constexpr (U8) {
                 // past the end of a ragged block: bytes whose conversion is not used (those frames are never stored)
                 if (TAIL && j >= n) return make_uint2(0u, 0u);
@@ -253,20 +296,39 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                 return r;
             }
         };
+        if constexpr (RING == 0) {
+            // (later blocks: their first group was fetched during the last group of the block before -- round 3; the
+            // stream used to drain at every block start, a full memory latency per 64 frames)
+            if (first_block) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) cur_raw[f] = load(f);
+                for (int f = 0; f < 4; ++f) cur_raw[f] = load(f);
+            }
+            first_block = false;
+        }
+        const bool has_next = !TAIL && blk + nwaves < nblk;
         // a ragged block stops after its last group with a real frame: a single window (n = 1, the reference's
         // deployment) then costs one group, not sixteen; a frame's arithmetic does not depend on what follows it
         const int ngrp = TAIL ? (int)((n + 3) >> 2) : 16;
         for (int G = 0; G < ngrp; ++G) {
-            // prefetch the next group (the last group re-reads itself: harmless, stays in bounds).  One group
-            // ahead is the measured optimum; two groups ahead (12 KB per wave in flight) was 10 % slower.
-            const int Gn = (G < 15) ? G + 1 : 15;
+            // prefetch the next group -- after a block's last group the first group of the wave's NEXT block (frame
+            // indices are linear in the block-relative j); the wave's very last group re-reads itself: harmless, stays
+            // in bounds.  One group ahead is the measured optimum; two groups ahead (12 KB per wave in flight) was 10 % slower.
+            const long Gn4 = (G < 15) ? 4 * (G + 1) : (has_next ? 64 * nwaves : 60);
+            if constexpr (RING > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring_cur[0]), "+v"(ring_cur[1]), "+v"(ring_cur[2]), "+v"(ring_cur[3]) :: "memory");
+                ring_issue(gi + RING);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING - 1)) : "memory");
+                ring_read(gi + 1, ring_nx);
+                __builtin_amdgcn_sched_barrier(0);     // copies, wait and reads stay at the top of the group
 #pragma unroll
-            for (int f = 0; f < 4; ++f) nx[f] = load(4 * Gn + f);
-            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the group
+                for (int f = 0; f < 4; ++f) cur[f] = make_float4(ring_cur[f].x, ring_cur[f].y, ring_cur[f].z, ring_cur[f].w);
+            } else {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) cur[f] = decode(cur_raw[f]);
+                for (int f = 0; f < 4; ++f) nx[f] = load(Gn4 + f);
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the group
+#pragma unroll
+                for (int f = 0; f < 4; ++f) cur[f] = decode(cur_raw[f]);
+            }
             float v[4][kC];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
@@ -372,8 +434,14 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                 }
             }
             if (myG == G) { r[0] = m[0]; r[1] = m[1]; r[2] = m[2]; }
+            if constexpr (RING > 0) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) cur_raw[f] = nx[f];
+                for (int f = 0; f < 4; ++f) ring_cur[f] = ring_nx[f];
+                ++gi;
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) cur_raw[f] = nx[f];
+            }
         }
         // ---- position w = 0 of both rows, all 64 frames at once: y = relu(b + K1*x[h][0]) (x[h][-1] = 0)
         if (!(ABL & 1)) { eI = e_tab[myframe * 2 + 0]; eQ = e_tab[myframe * 2 + 1]; }
@@ -410,6 +478,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
             }
         }
     }
+    if constexpr (RING > 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the clamped tail copies have landed
 }
 
 }  // namespace
@@ -551,7 +620,32 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
         MDC_DEP_PROBE(1, 16) MDC_DEP_PROBE(2, 48) MDC_DEP_PROBE(3, 32)
 #undef MDC_DEP_PROBE
 #endif
-        if (tap_dense) {
+        // Alternates build, model created under MDC_DEP_RING=N (N in 2, 3, 4, 6, 8): T1's frames through the per-wave
+        // LDS-DMA ring (see the kernel) instead of direct loads.  Bit-identical and SLOWER at every depth (round 3,
+        // profiles/r03_t1_f32_ring_ab.log: 4.05 / 3.9 / 3.9 / 3.35 / 3.45e9 frames/s against 4.2-4.3e9 in the same run):
+        // the ring's LDS limits a CU to 16 / 12 / 8 / 4 waves, and this all-VALU kernel needs its 32 to cover the DPP
+        // reduce-scatter's latencies.  The grid is exactly the resident set, so every wave walks one long stream of groups.
+        int ring = 0;
+#ifdef MDC_ALTERNATES
+        if (m->alt_ring > 0 && F == 3 && !tap_dense) ring = m->alt_ring;
+#endif
+        if (ring > 0) {
+#ifdef MDC_ALTERNATES
+#define MDC_LAUNCH_RING(R) do { \
+            constexpr int lds = 4 * R * 4096, per_cu = (160 * 1024) / (lds + 2048); \
+            long g = (nfull / 64 + 3) / 4; if (g > 256L * per_cu) g = 256L * per_cu; \
+            MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_fwd_kernel<3, 0, 0, false, false, false, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, false, false, false, R>), dim3((unsigned)g), dim3(256), lds, s, x, nfull, wp, probs, labels, tap_dense); } while (0)
+            switch (ring) {
+                case 2: MDC_LAUNCH_RING(2); break;
+                case 3: MDC_LAUNCH_RING(3); break;
+                case 6: MDC_LAUNCH_RING(6); break;
+                case 8: MDC_LAUNCH_RING(8); break;
+                default: MDC_LAUNCH_RING(4); break;
+            }
+#undef MDC_LAUNCH_RING
+#endif
+        } else if (tap_dense) {
             if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
             else if (piv) hipLaunchKernelGGL((deployed_fwd_kernel<10, 2, 0, false, false, true>), dim3(grid), dim3(256), 0, s, x, nfull, wpv, probs, labels, tap_dense);
             else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);

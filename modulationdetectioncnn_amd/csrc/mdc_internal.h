@@ -80,6 +80,7 @@ struct mdc_model {
     // selecting environment variables ONCE into this field (mdc::kAlt* bits).  Always 0 in the product library: no entry
     // point under mdc_forward* reads the environment.
     int alt = 0;
+    int alt_ring = -1;           // alternates build, MDC_DEP_RING=N: ring depth of the 3-filter f32 kernel (0 = direct loads); -1 = the product's choice
     float fp8_input_absmax = 0.02f;
     int fp8_feat_scale_log2 = 0;
 
