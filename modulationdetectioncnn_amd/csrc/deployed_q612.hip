@@ -21,6 +21,17 @@
 // of the block's frame i, and after 64 frames every lane finishes one frame: position w = 0 (x[-1] = 0; uniform
 // weights), bias, ReLU, first-max label, 768 + 256 B of coalesced stores.
 // HBM: 1 KiB in, 4*C + 4 B out per frame.
+//
+// Round 3, measured and NOT kept -- both forms bit-exact on the whole Q6.12 suite:
+//  * the pair from 24-bit multiplies: with b = bh*4096 + bl, floor(m / 4096) = a*bh + c*dh + ((a*bl + c*dl) >> 12), every
+//    product < 2^30 (v_mul_i32_i24 / v_mad_i32_i24), and {m[35], m[28:12]} = {r[23], r[16:0]} of that r.  T1 1.21e9
+//    against 1.59e9 frames/s, T2 4.4e8 against 4.8e8: v_mad_i64_i32 is not a quarter-rate instruction on gfx950 -- it
+//    issues at HALF the plain VALU rate (9.5 against 4.9 cycles per wave-instruction, tools/microbench/imul_rate.hip,
+//    profiles/r03_imul_rate.log), so two of them (19) beat two v_mul_i32_i24 + two v_mad_i32_i24 + shift + add (31);
+//  * four frames at a time with the f32 kernel's bank-masked DPP reduce-scatter instead of the shuffle butterfly
+//    (10 VALU per frame instead of 18 ds_bpermute + 18 adds) on top of the 64-bit pairs: T1 1.47e9 (118 VGPRs), and
+//    F = 10 does not fit its 120 weight registers + four frames' operands in 256 VGPRs (241 spills, 2.8e8).
+// The kernel below is round 2's.
 #include "mdc_internal.h"
 
 #include <cmath>
