@@ -83,6 +83,7 @@ struct mdc_model {
     int alt_ring = -1;           // alternates build, MDC_DEP_RING=N: ring depth of the 3-filter f32 kernel (0 = direct loads); -1 = the product's choice
     float fp8_input_absmax = 0.02f;
     int fp8_feat_scale_log2 = 0;
+    int feat_scale_log2 = 0;     // 16-bit modes: the workspace features are the true ones times 2^feat_scale_log2 (taps undo it)
 
     // profiling is the one piece of state mdc_forward touches on a finalized model: the event lists are guarded, so
     // forwards of one model from several host threads stay safe with profiling on

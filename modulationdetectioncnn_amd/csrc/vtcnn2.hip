@@ -452,7 +452,7 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
     if (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) {
         const long total = (long)n * kFeat;
         // fp8 mode keeps its features multiplied by a power of two (dense1's weights carry the inverse)
-        const float unscale = m->dtype == MDC_FP8 ? std::ldexp(1.f, -m->fp8_feat_scale_log2) : 1.f;
+        const float unscale = std::ldexp(1.f, -m->feat_scale_log2);      // the 16-bit modes keep their features times a power of two
         if (m->dtype != MDC_F32)
             hipLaunchKernelGGL(vt_unpermute_kernel<unsigned short>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned short*>(feat), (long)n, tap, unscale);
         else

@@ -24,6 +24,9 @@
 // bf16 operands, and the conv launcher.  vtcnn2_bf16_sched.hip holds the production (asm-sequenced) conv
 // kernel, vtcnn2_bf16_dense1.hip the dense1 GEMM.
 #include "vtcnn2_bf16_common.h"
+#include "vtcnn2_sched_common.h"
+
+#include <cmath>
 
 #include <cstdlib>
 #include <cstring>
@@ -296,13 +299,14 @@ int vtcnn2_bf16_pack(mdc_model* m) {
             for (int lane = 0; lane < 64; ++lane) {
                 const int ch = 64 * q + 16 * ct + (lane & 15), kg = lane >> 4;
                 unsigned short* d = &a1[(((size_t)q * 4 + ct) * 64 + lane) * 4];
+                const float sc = std::ldexp(1.f, -kFeatShift);      // as the production kernel's operands: activations x 2^-kFeatShift
                 if (kg == 3) {
-                    const unsigned short hi = f2bf(b1[ch]);
+                    const unsigned short hi = f2bf(b1[ch] * sc);
                     d[0] = hi;
-                    d[1] = f2bf(b1[ch] - bf2f(hi));
+                    d[1] = f2bf(b1[ch] * sc - bf2f(hi));
                 } else {
                     for (int t = 0; t < 3; ++t) {
-                        const float kv = k1[ch * 3 + t];
+                        const float kv = k1[ch * 3 + t] * sc;
                         const unsigned short hi = f2bf(kv);
                         d[t] = (kg == 2) ? f2bf(kv - bf2f(hi)) : hi;
                     }
@@ -313,6 +317,14 @@ int vtcnn2_bf16_pack(mdc_model* m) {
 #else
     (void)k1; (void)b1; (void)k2;
 #endif
+    // The bf16 mode's activations and features carry 2^-kFeatShift (vtcnn2_sched_common.h: ReLU in the bf16 conversion's
+    // clamp bit): conv2's bias goes with them, dense1's weights take the factor back -- powers of two, exact everywhere
+    {
+        std::vector<float> b2s(m->hb[1]);
+        for (float& v : b2s) v = std::ldexp(v, -kFeatShift);
+        if ((rc = upload(m, 2, b2s.data(), b2s.size() * sizeof(float)))) return rc;
+    }
+    m->feat_scale_log2 = -kFeatShift;
     // dense1: transposed and K-tiled [k'/64][n][k'%64] with k' = w*80 + o  <-  reference row o*132 + w
     const float* w1 = m->hk[2].data();
     std::vector<unsigned short> w1t((size_t)kHid * kFeat);
@@ -321,7 +333,7 @@ int vtcnn2_bf16_pack(mdc_model* m) {
             const float* src = w1 + (size_t)(o * kW2 + w) * kHid;
             // tile-contiguous: [k-tile of 64][hidden unit][64], so a K-tile of the GEMM's B operand is one 32 KiB block
             const int kk = w * kC2 + o;
-            for (int nn = 0; nn < kHid; ++nn) w1t[((size_t)(kk >> 6) * kHid + nn) * 64 + (kk & 63)] = f2bf(src[nn]);
+            for (int nn = 0; nn < kHid; ++nn) w1t[((size_t)(kk >> 6) * kHid + nn) * 64 + (kk & 63)] = f2bf(std::ldexp(src[nn], kFeatShift));
         }
     if ((rc = upload(m, 3, w1t.data(), w1t.size() * 2))) return rc;
     return vtcnn2_bf16_pack_sched(m);      // operands of the asm-sequenced conv kernel (its own K order)

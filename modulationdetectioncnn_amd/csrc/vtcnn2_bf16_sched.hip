@@ -3,6 +3,7 @@
 #include "vtcnn2_bf16_common.h"
 #include "vtcnn2_sched_common.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -26,12 +27,14 @@ namespace {
 // gaps and used v_pk_add_f32: its non-MFMA work cost its full issue time, 600 cycles on a 1100-cycle MFMA floor.)
 //
 // Step v (accumulators: a0 = output v+2, fresh; a1 = v+1; a2 = v, completes), 62 MFMAs:
-//   T2  tap 2 (20)      gaps: finish of output v-1 (21 VALU: sum of the 4 partials, ReLU, bf16), conv1 operand dwords
+//   T2  tap 2 (20)      gaps: finish of output v-1 (18 VALU: sum of the 4 partials, ReLU + bf16 in the conversion's clamp
+//                       bit), conv1 operand dwords
 //   C1  conv1(v+1): 2 x v_mfma_f32_32x32x16_bf16 (M = 32 channels, N = 16 frames x 2 I/Q rows, K = 16 slots)
-//   T1  tap 1 (20)      gaps: the 2 feature stores of output v-1, ds_writes of a2 = partial(v), pack VALU of conv1(v+1)
+//   T1  tap 1 (20)      gaps: the 2 feature stores of output v-1, ds_writes of a2 = partial(v), pack of conv1(v+1)
 //   T0  tap 0 (20, 5 fresh with C = conv2 bias on wave 0)
-//                       gaps: lgkmcnt(0)+s_barrier after the 3rd MFMA, 8 ds_reads of partial(v), pack VALU,
-//                       every 2nd step one LDS read of conv1 operands
+//                       gaps: last pack VALU, lgkmcnt(0)+s_barrier after the 3rd MFMA, 8 ds_reads of partial(v),
+//                       every 2nd step one LDS read of conv1 operands; nine gaps stay empty
+// Round 3: ReLU moved into the clamp bit of the bf16 conversions (19 VALU fewer per step: no gap holds two VALU any more).
 // conv1 on the 32x32 shape: the MFMA's column is (frame, row), so its result holds BOTH rows of a frame in lanes
 // f+16h (+32 for the upper k-half): packed to bf16 it is a B operand of conv2's 16x16x32 MFMA whose K index mixes
 // rows and channels -- conv2 sums over both, so only the weight fragments' K order changes (packed to match on
@@ -98,18 +101,14 @@ __device__ __forceinline__ void sch_tap(SchedState& st, f32x4 (&acc)[5]) {
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kNV]), "v"(b));
     }
 }
-// pack instruction N (0..31) of conv1's X into Bf[SP]: unit u = N>>1 = (channel block ct, result register pair j);
-// even N = v_cvt_pk_bf16_f32 of two channels, odd N = ReLU on the packed pair (negative bf16 <=> negative int16)
-template <int SP, int N>
+// pack instruction U (0..15) of conv1's X into Bf[SP]: unit U = (channel block ct, result register pair j): ReLU and bf16
+// pack of two channels in ONE v_cvt_pk_bf16_f32 with the clamp bit (values below 1: kFeatShift, vtcnn2_sched_common.h)
+template <int SP, int U>
 __device__ __forceinline__ void sch_packop(SchedState& st) {
-    constexpr int u = N >> 1, CT = u >> 3, j = u & 7;
+    constexpr int CT = U >> 3, j = U & 7;
     unsigned& d = st.Bf[SP][CT][j >> 2][j & 3];
-    if constexpr ((N & 1) == 0) {
-        const float lo = st.X[CT][2 * j], hi = st.X[CT][2 * j + 1];
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
-    } else {
-        asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(d));
-    }
+    const float lo = st.X[CT][2 * j], hi = st.X[CT][2 * j + 1];
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(lo), "v"(hi));
 }
 // One position step.  V12 = v mod 12 fixes every register choice: Bf/partial-buffer parity (v&1), the accumulator
 // roles (v%3), the role of position v+1 in its operand chunk ((v+1)&3) and the chunk slots (((v+1)>>2)%3).
@@ -134,7 +133,7 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     const unsigned load_addr = st.im_addr + ((v >> 2) * 16 + (kLoadEven ? 16 : 24));      // 8 bytes per entry
     FinTmp ft;
     FinOut fo;
-#define FIN(K) do { if (!FIRST && kFin) sch_fin<K>(st, ft, fo); } while (0)
+#define FIN(K) do { if (!FIRST && kFin) sch_fin_clamp<K>(st, ft, fo); } while (0)
 #define PREP(I) do { if (!LAST && kC1 && ABL != 11) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST && kC1) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
 #define ST(W) do { if (!FIRST && kFin) { if (ABL == 7) asm volatile("" ::"v"(fo.o0), "v"(fo.o1), "v"(fo.tt)); else if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
@@ -149,7 +148,7 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
         else if (kExch) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
     sch_wait_lds(st);      // partial(v-1) and any operand words: read during T0 of the previous step
-    // ---- T2: tap 2 -> a2 complete.  gaps: finish of output v-1 (F0..F16); the conv1 operand dwords of v+1 in the last four
+    // ---- T2: tap 2 -> a2 complete.  gaps: finish of output v-1 (F0..F15); the conv1 operand dwords of v+1 in the last four
     sch_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); FIN(0);
     sch_tap<PAR, 2, 1>(st, a2); FIN(1);
     sch_tap<PAR, 2, 2>(st, a2); FIN(2);
@@ -166,16 +165,17 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     sch_tap<PAR, 2, 13>(st, a2); FIN(13);
     sch_tap<PAR, 2, 14>(st, a2); FIN(14);
     sch_tap<PAR, 2, 15>(st, a2); FIN(15);
-    sch_tap<PAR, 2, 16>(st, a2); FIN(16); PREP(0);
+    sch_tap<PAR, 2, 16>(st, a2); PREP(0);
     sch_tap<PAR, 2, 17>(st, a2); PREP(1);
     sch_tap<PAR, 2, 18>(st, a2); PREP(2);
     sch_tap<PAR, 2, 19>(st, a2); PREP(3);
     // ---- C1: conv1(v+1): two 32x32x16 MFMAs, the only ones that write VGPRs.  Their 32-cycle gaps take two VALU and
     //      one LDS instruction each: end of the finish, first two ds_writes of partial(v).  NO feature store here (hazards)
-    C1M(0); FIN(17); FIN(18); WR(0);
-    C1M(1); FIN(19); FIN(20); WR(1);
+    C1M(0); FIN(16); FIN(17); WR(0);
+    C1M(1); WR(1);
     // ---- T1: tap 1.  gaps: the two feature stores, three more ds_writes (the four waves share the CU's LDS store path,
     //      13 cycles per ds_write_b128: one every third gap keeps it unsaturated), pack of conv1(v+1) one VALU each
+    //      (unit u reads conv1 result block u >> 3: the first one sits five MFMAs behind C1M(0), unit 8 twelve behind C1M(1))
     sch_tap<PAR, 1, 0>(st, a1); ST(0);
     sch_tap<PAR, 1, 1>(st, a1); WR(2);
     sch_tap<PAR, 1, 2>(st, a1); ST(1);
@@ -196,10 +196,10 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     sch_tap<PAR, 1, 17>(st, a1); PK(12);
     sch_tap<PAR, 1, 18>(st, a1); PK(13);
     sch_tap<PAR, 1, 19>(st, a1); PK(14);
-    // ---- T0: tap 0 (5 fresh).  gaps: operand load (every 2nd step), hand-off, the 8 reads of partial(v), rest of the pack
-    sch_tap<PAR, 0, 0>(st, a0); PK(15); LD();
-    sch_tap<PAR, 0, 1>(st, a0); PK(16);
-    sch_tap<PAR, 0, 2>(st, a0); PK(17); HANDOFF();
+    // ---- T0: tap 0 (5 fresh).  gaps: last pack, hand-off, the 8 reads of partial(v), operand load (every 2nd step)
+    sch_tap<PAR, 0, 0>(st, a0); PK(15);
+    sch_tap<PAR, 0, 1>(st, a0);
+    sch_tap<PAR, 0, 2>(st, a0); HANDOFF();
     sch_tap<PAR, 0, 3>(st, a0); RD(0);
     sch_tap<PAR, 0, 4>(st, a0); RD(1);
     sch_tap<PAR, 0, 5>(st, a0); RD(2);
@@ -208,15 +208,15 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     sch_tap<PAR, 0, 8>(st, a0); RD(5);
     sch_tap<PAR, 0, 9>(st, a0); RD(6);
     sch_tap<PAR, 0, 10>(st, a0); RD(7);
-    sch_tap<PAR, 0, 11>(st, a0); PK(18); PK(19);
-    sch_tap<PAR, 0, 12>(st, a0); PK(20); PK(21);
-    sch_tap<PAR, 0, 13>(st, a0); PK(22); PK(23);
-    sch_tap<PAR, 0, 14>(st, a0); PK(24); PK(25);
-    sch_tap<PAR, 0, 15>(st, a0); PK(26); PK(27);
-    sch_tap<PAR, 0, 16>(st, a0); PK(28);
-    sch_tap<PAR, 0, 17>(st, a0); PK(29);
-    sch_tap<PAR, 0, 18>(st, a0); PK(30);
-    sch_tap<PAR, 0, 19>(st, a0); PK(31);
+    sch_tap<PAR, 0, 11>(st, a0); LD();      // (behind the hand-off: its lgkmcnt(0) does not have to wait for this read)
+    sch_tap<PAR, 0, 12>(st, a0);
+    sch_tap<PAR, 0, 13>(st, a0);
+    sch_tap<PAR, 0, 14>(st, a0);
+    sch_tap<PAR, 0, 15>(st, a0);
+    sch_tap<PAR, 0, 16>(st, a0);
+    sch_tap<PAR, 0, 17>(st, a0);
+    sch_tap<PAR, 0, 18>(st, a0);
+    sch_tap<PAR, 0, 19>(st, a0);
     if (ABL == 10 && !LAST) asm volatile("" ::"v"(st.X[0]), "v"(st.X[1]));      // probe 10: conv1 results stay live (async MFMA write)
 #undef FIN
 #undef PREP
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
         sch_wait_lds(st);
         sch_conv1_mfma<0, 0, 0>(st); sch_conv1_mfma<0, 0, 1>(st);
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(st.X[0]), "+v"(st.X[1]));
-        [&]<int... N>(std::integer_sequence<int, N...>) { (sch_packop<0, N>(st), ...); }(std::make_integer_sequence<int, 32>{});
+        [&]<int... N>(std::integer_sequence<int, N...>) { (sch_packop<0, N>(st), ...); }(std::make_integer_sequence<int, 16>{});
         asm volatile("s_nop 1");
 
         sch_step<0, true, false, ABL, RANGE>(st, S, q, fbase, acc, wlo);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
             if (rng < 10) {      // finish of output S+13; the accumulators of S+14, S+15 are dropped
                 FinOut fo;
                 sch_wait_lds(st);
-                sch_fin_all(st, fo);
+                sch_fin_all_clamp(st, fo);
                 sch_store<0>(fo, fbase, vt, q, st.gs);
                 sch_store<1>(fo, fbase, vt, q, st.gs);
                 asm volatile("s_nop 7\n\ts_nop 7" ::"a"(acc[0][0]), "a"(acc[1][0]), "a"(acc[2][0]));      // in-flight MFMA results land before the registers die
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
         auto finish_store = [&](int w) {
             FinOut fo;
             sch_wait_lds(st);
-            sch_fin_all(st, fo);
+            sch_fin_all_clamp(st, fo);
             sch_store<0>(fo, fbase, w, q, st.gs);
             sch_store<1>(fo, fbase, w, q, st.gs);
         };
@@ -434,16 +434,18 @@ int vtcnn2_bf16_pack_sched(mdc_model* m) {
             for (int lane = 0; lane < 64; ++lane) {
                 const int ch = 64 * q + 32 * ct + (lane & 31), khalf = lane >> 5;
                 unsigned short* d = &a1[(((size_t)q * 2 + ct) * 64 + lane) * 8];
+                // taps and bias times 2^-kFeatShift (exact: the hi / lo split of a scaled value is the scaled split)
+                const float sc = std::ldexp(1.f, -kFeatShift);
                 unsigned short th[3], tl[3];
                 for (int t = 0; t < 3; ++t) {
-                    th[t] = f2bf(k1[ch * 3 + t]);
-                    tl[t] = f2bf(k1[ch * 3 + t] - bf2f(th[t]));
+                    th[t] = f2bf(k1[ch * 3 + t] * sc);
+                    tl[t] = f2bf(k1[ch * 3 + t] * sc - bf2f(th[t]));
                 }
                 if (khalf == 0) {
                     d[0] = th[0]; d[1] = th[1]; d[2] = th[0]; d[3] = th[1]; d[4] = th[2]; d[6] = th[2];
                 } else {
-                    const unsigned short bh = f2bf(b1[ch]);
-                    d[0] = tl[0]; d[1] = tl[1]; d[2] = bh; d[3] = f2bf(b1[ch] - bf2f(bh)); d[4] = tl[2];
+                    const unsigned short bh = f2bf(b1[ch] * sc);
+                    d[0] = tl[0]; d[1] = tl[1]; d[2] = bh; d[3] = f2bf(b1[ch] * sc - bf2f(bh)); d[4] = tl[2];
                 }
             }
     return upload(m, 7, a1.data(), a1.size() * 2);

@@ -346,6 +346,7 @@ int vtcnn2_fp8_pack(mdc_model* m) {
     const int sa = (int)std::floor(std::log2(224.f / c1bound));
     const float fsw = std::ldexp(1.f, sw), fsa = std::ldexp(1.f, sa);
     m->fp8_feat_scale_log2 = sa + sw;
+    m->feat_scale_log2 = sa + sw;
 
     std::vector<unsigned char> wq((size_t)4 * kF8Frags * 64 * 32);
     for (int q = 0; q < 4; ++q)
