@@ -12,14 +12,23 @@
 //     instruction was probed with exact integer data (tools/microbench/mfma_fp8_probe.hip): row / column on
 //     lane&15, and the k index a function of (lane>>4, byte) common to A and B -- so the weight fragment simply
 //     stores, at (lane>>4, byte), the weight of the (row h, channel) the activation operand carries there;
-//   * ReLU is v_med3_f32(x, 0, 448) on the conv1 results (it also saturates at the e4m3 maximum, so an input beyond
-//     the stated range clips instead of turning into NaN) before v_cvt_pk_fp8_f32 (48 pack VALU per step instead of 32): with
-//     17 long MFMAs per step the kernel is VALU-issue-bound rather than MFMA-bound;
-//   * SCALING (host side only): e4m3 spans 2^-9 .. 448.  conv1's taps and bias are multiplied by 2^sa and conv2's
-//     weights by 2^sw (powers of two: exact), conv2's bias by 2^(sa+sw); the features come out multiplied by
-//     2^(sa+sw) and dense1's weights are divided by it.  sa is chosen from the largest |sample| the caller expects
-//     (mdc_set_fp8_input_absmax, default 0.02 = the reference's frames); a larger input overflows
-//     e4m3 -- "fp8 (scaled inputs)" in the survey's words.
+//   * ReLU + e4m3 pack of the conv1 results is TWO VALU per pair (round 3; rounds 1-2: two v_med3_f32(x, 0, 448) + one
+//     v_cvt_pk_fp8_f32 = three): v_cvt_pk_bf16_f32 with the VOP3 clamp bit (ReLU and clamp to [0, 1] inside the
+//     conversion; the conv1 operands carry 2^(sa-9), so the e4m3 range 0 .. 448 is 0 .. 0.875 there) and
+//     v_cvt_scalef32_pk_fp8_bf16 with scale 2^-9 (probed: tools/microbench/cvt_fp8_bf16_probe.hip -- the result is
+//     e4m3(src / scale), written to the half of the dword op_sel names, and with MODE.FP16_OVFL = 1, which the kernel sets,
+//     a value beyond 448 saturates instead of turning into NaN: an input beyond the stated range still clips).  32 pack
+//     VALU per step instead of 48, and the finish's three v_pk_max_i16 go the same way (clamp bit): with 17 long MFMAs per
+//     step the kernel is VALU-issue-bound, so this is where its time is.  The activations are rounded f32 -> bf16 -> e4m3
+//     (the second rounding sees 8 significant bits instead of 24: a value within 2^-9 of an e4m3 tie may land on the
+//     other side of it; 2^-9 against e4m3's own 2^-4);
+//   * SCALING (host side and the MFMA's own block-scale operand): e4m3 spans 2^-9 .. 448.  conv1's taps and bias carry
+//     2^(sa-9) (see above: its e4m3 activations are X * 2^sa), conv2's weights 2^sw (powers of two: exact); the MFMA's
+//     E8M0 scale operand of B is 2^-(sa+sw+kFeatShift), so the accumulators -- and the bf16 features -- are the true
+//     values times 2^-kFeatShift exactly as in the bf16 mode (vtcnn2_sched_common.h): conv2's bias carries 2^-kFeatShift,
+//     dense1's weights 2^+kFeatShift, the finish uses the clamp form.  sa is chosen from the largest |sample| the caller
+//     expects (mdc_set_fp8_input_absmax, default 0.02 = the reference's frames); a larger input
+//     saturates -- "fp8 (scaled inputs)" in the survey's words.
 // Parity: unpinned like every T3 result (no weights bundled); checked against the f64 oracle at 6e-2 of max|logit|.
 #include "vtcnn2_bf16_common.h"
 #include "vtcnn2_sched_common.h"
@@ -41,10 +50,11 @@ struct Fp8State {
     f32x4 bias[5];            // scaled conv2 bias tiles: C operand of the fresh MFMAs (wave 0; zeros on waves 1-3)
     u32x4 A1[2];              // conv1 A operands (scaled), 32 channels x 16 k-slots each
     unsigned Bf[2][8];        // [step parity][dword]: B operand of conv2 (32 fp8), as scalars
-    unsigned one;             // E8M0 scales 2^0 for the MFMA
-    float sat;                // 448 = largest e4m3 value
+    unsigned one;             // E8M0 scales 2^0 for the MFMA's A operand
+    unsigned scb;             // E8M0 scales 2^-(sa+sw+kFeatShift) for its B operand (every byte the same)
+    float sc9;                // 2^-9: divisor of v_cvt_scalef32_pk_fp8_bf16
     f32x16 X[2];
-    float R[2][16];           // ReLU'd conv1 results (asm cannot update a vector element in place)
+    unsigned T[16];           // ReLU'd conv1 results as packed bf16 pairs
     f32x4 rp[4];
     float rc[4];
     u32x4 L0[3];
@@ -62,31 +72,31 @@ __device__ __forceinline__ void f8_tap(Fp8State& st, f32x4 (&acc)[5]) {
     constexpr int IDX = J * 5 + OT;
     const u32x8 b = u32x8{st.Bf[SP][0], st.Bf[SP][1], st.Bf[SP][2], st.Bf[SP][3], st.Bf[SP][4], st.Bf[SP][5], st.Bf[SP][6], st.Bf[SP][7]};
     if constexpr (J == 0) {
-        if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "a"(st.bias[OT]), "v"(st.one));
-        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "a"(st.bias[OT]), "v"(st.one));
+        if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "a"(st.bias[OT]), "v"(st.one), "v"(st.scb));
+        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]" : "=&a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "a"(st.bias[OT]), "v"(st.one), "v"(st.scb));
     } else if constexpr (PAD) {
-        if constexpr (IDX < kF8NV) asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "v"(st.one));
-        else asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "v"(st.one));
+        if constexpr (IDX < kF8NV) asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "v"(st.one), "v"(st.scb));
+        else asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "v"(st.one), "v"(st.scb));
     } else {
-        if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "v"(st.one));
-        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "v"(st.one));
+        if constexpr (IDX < kF8NV) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "v"(st.Wv[IDX]), "v"(b), "v"(st.one), "v"(st.scb));
+        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc[OT]) : "a"(st.Wa[IDX - kF8NV]), "v"(b), "v"(st.one), "v"(st.scb));
     }
 }
-// pack of conv1's results into Bf[SP]: RELU<N> (N = 0..31: v_max_f32 of result register N&15 of block N>>4 into R),
-// then CVT<K> (K = 0..15: two registers -> two fp8 in one half of dword K>>1).  Byte jb = 16*ct + r of the operand
-// holds result register r of channel block ct.
-template <int N>
-__device__ __forceinline__ void f8_relu(Fp8State& st) {
-    const float x = st.X[N >> 4][N & 15];
-    // ReLU and saturation at the e4m3 maximum in one VALU: median(x, 0, 448)
-    asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(st.R[N >> 4][N & 15]) : "v"(x), "v"(st.sat));
+// pack of conv1's results into Bf[SP], unit K (0..15) = result registers (r0, r0+1) of channel block ct, destined for
+// half K&1 of dword d = K>>1 (byte jb = 16*ct + r of the operand holds result register r of channel block ct):
+// PKB<K> = v_cvt_pk_bf16_f32 with the clamp bit (ReLU; values in [0, 0.875] for inputs inside the stated range),
+// CV<K> = v_cvt_scalef32_pk_fp8_bf16 (divide by 2^-9, round to e4m3, saturate at 448 under MODE.FP16_OVFL)
+template <int K>
+__device__ __forceinline__ void f8_pkb(Fp8State& st) {
+    constexpr int d = K >> 1, ct = d >> 2, r0 = 4 * (d & 3) + 2 * (K & 1);
+    const float lo = st.X[ct][r0], hi = st.X[ct][r0 + 1];
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(st.T[K]) : "v"(lo), "v"(hi));
 }
 template <int SP, int K>
 __device__ __forceinline__ void f8_cvt(Fp8State& st) {
-    constexpr int d = K >> 1, ct = d >> 2, r0 = 4 * (d & 3) + 2 * (K & 1);
-    const float lo = st.R[ct][r0], hi = st.R[ct][r0 + 1];
-    if constexpr ((K & 1) == 0) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(st.Bf[SP][d]) : "v"(lo), "v"(hi));
-    else asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(st.Bf[SP][d]) : "v"(lo), "v"(hi));
+    constexpr int d = K >> 1;
+    if constexpr ((K & 1) == 0) asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(st.Bf[SP][d]) : "v"(st.T[K]), "v"(st.sc9));
+    else asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(st.Bf[SP][d]) : "v"(st.T[K]), "v"(st.sc9));
 }
 
 // One position step: 15 conv2 MFMAs + 2 conv1 MFMAs, every gap 32 cycles (2 VALU, or 1 VALU + 1 LDS, ride for free).
@@ -103,12 +113,12 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
     const unsigned load_addr = st.im_addr + ((v >> 2) * 16 + (kLoadEven ? 16 : 24));
     FinTmp ft;
     FinOut fo;
-#define FIN(K) do { if (!FIRST) sch_fin<K>(st, ft, fo); } while (0)
+#define FIN(K) do { if (!FIRST) sch_fin_clamp<K>(st, ft, fo); } while (0)
 #define PREP(I) do { if (!LAST) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
 #define ST(W) do { if (!FIRST) { if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
 #define WR(OT) sch_part_write<PAR, OT>(st, a2[OT])
-#define RL(N) do { if (!LAST) f8_relu<N>(st); } while (0)
+#define PKB(K) do { if (!LAST) f8_pkb<K>(st); } while (0)
 #define CV(K) do { if (!LAST) f8_cvt<PN, K>(st); } while (0)
 #define RD(R) sch_red_load1<PAR, R>(st)
 #define LD() do { if (kLoadEven) sch_load_even<LSLOT>(st, load_addr); else if (kLoadOdd) sch_load_odd(st, load_addr); } while (0)
@@ -116,33 +126,36 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
     sch_wait_lds(st);
-    // ---- T2: tap 2 -> a2 complete; finish of output v-1, conv1 operand dwords of v+1
-    f8_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); FIN(0); FIN(1); FIN(2); FIN(3);
-    f8_tap<PAR, 2, 1>(st, a2); FIN(4); FIN(5); FIN(6); FIN(7);
-    f8_tap<PAR, 2, 2>(st, a2); FIN(8); FIN(9); FIN(10); FIN(11);
-    f8_tap<PAR, 2, 3>(st, a2); FIN(12); FIN(13); FIN(14); FIN(15); PREP(0); PREP(1);
-    f8_tap<PAR, 2, 4>(st, a2); FIN(16); FIN(17); FIN(18); PREP(2); PREP(3);
+    // 54 VALU per step (rounds 1-2: 73) spread evenly over the 17 gaps: three per gap, four in three of them (a 32-cycle gap
+    // takes two VALU for free, a third costs 4 cycles, a fourth 8 more: tools/microbench/mfma_gap.hip)
+    // ---- T2: tap 2 -> a2 complete; finish of output v-1 (18 VALU, ReLU in the conversions' clamp bit), conv1 operand dwords of v+1
+    f8_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); FIN(0); FIN(1); FIN(2);
+    f8_tap<PAR, 2, 1>(st, a2); FIN(3); FIN(4); FIN(5);
+    f8_tap<PAR, 2, 2>(st, a2); FIN(6); FIN(7); FIN(8);
+    f8_tap<PAR, 2, 3>(st, a2); FIN(9); FIN(10); PREP(0); PREP(1);
+    f8_tap<PAR, 2, 4>(st, a2); FIN(11); PREP(2); PREP(3);
     // ---- C1: conv1(v+1), the only MFMAs that write VGPRs: no feature store next to them (vtcnn2_bf16_sched.hip)
-    C1M(0); FIN(19); FIN(20); WR(0);
-    C1M(1); WR(1);
-    // ---- T1: tap 1; feature stores, the rest of the ds_writes, ReLU / fp8 pack of conv1(v+1)
-    f8_tap<PAR, 1, 0>(st, a1); ST(0); WR(2); RL(0); RL(1); RL(2); RL(3);
-    f8_tap<PAR, 1, 1>(st, a1); ST(1); RL(4); RL(5); RL(6); RL(7); RL(8); RL(9);
-    f8_tap<PAR, 1, 2>(st, a1); WR(3); RL(10); RL(11); RL(12); RL(13); RL(14); RL(15); LD();
-    f8_tap<PAR, 1, 3>(st, a1); WR(4); CV(0); CV(1); CV(2); CV(3); CV(4); CV(5);
-    f8_tap<PAR, 1, 4>(st, a1); CV(6); CV(7); RL(16); RL(17); RL(18); RL(19);
+    C1M(0); FIN(12); FIN(13); FIN(14); WR(0);
+    C1M(1); FIN(15); FIN(16); FIN(17); WR(1);
+    // ---- T1: tap 1; feature stores, the rest of the ds_writes, ReLU / fp8 pack of conv1(v+1) (units 0..7 read the first
+    //      conv1 result block, two long MFMAs behind its MFMA; 8..15 the second, four behind)
+    f8_tap<PAR, 1, 0>(st, a1); ST(0); WR(2); PKB(0); PKB(1); PKB(2);
+    f8_tap<PAR, 1, 1>(st, a1); ST(1); PKB(3); PKB(4); PKB(5);
+    f8_tap<PAR, 1, 2>(st, a1); WR(3); PKB(6); PKB(7); CV(0); LD();
+    f8_tap<PAR, 1, 3>(st, a1); WR(4); CV(1); CV(2); CV(3);
+    f8_tap<PAR, 1, 4>(st, a1); PKB(8); PKB(9); CV(4);
     // ---- T0: tap 0 (fresh, C = bias); hand-off, reads of partial(v), rest of the pack
-    f8_tap<PAR, 0, 0>(st, a0); RL(20); RL(21); RL(22); RL(23); RL(24); RL(25);
-    f8_tap<PAR, 0, 1>(st, a0); HANDOFF(); RL(26); RL(27); RL(28); RL(29); RL(30); RL(31); RD(0); RD(1);
-    f8_tap<PAR, 0, 2>(st, a0); CV(8); CV(9); CV(10); CV(11); RD(2); RD(3);
-    f8_tap<PAR, 0, 3>(st, a0); CV(12); CV(13); CV(14); CV(15); RD(4); RD(5);
-    f8_tap<PAR, 0, 4>(st, a0); RD(6); RD(7);
+    f8_tap<PAR, 0, 0>(st, a0); PKB(10); PKB(11); CV(5);
+    f8_tap<PAR, 0, 1>(st, a0); HANDOFF(); PKB(12); PKB(13); CV(6); RD(0); RD(1);
+    f8_tap<PAR, 0, 2>(st, a0); PKB(14); PKB(15); CV(7); CV(8); RD(2); RD(3);
+    f8_tap<PAR, 0, 3>(st, a0); CV(9); CV(10); CV(11); CV(12); RD(4); RD(5);
+    f8_tap<PAR, 0, 4>(st, a0); CV(13); CV(14); CV(15); RD(6); RD(7);
 #undef FIN
 #undef PREP
 #undef C1M
 #undef ST
 #undef WR
-#undef RL
+#undef PKB
 #undef CV
 #undef RD
 #undef LD
@@ -155,7 +168,7 @@ template <bool U8, bool RANGE = false>
 __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __restrict__ x, long n,
                                                              const u32x8* __restrict__ wq, const u32x4* __restrict__ a1q,
                                                              const float* __restrict__ b2, unsigned short* __restrict__ feat,
-                                                             long hop2, float scale) {
+                                                             long hop2, float scale, unsigned scale_b_e8m0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* img = reinterpret_cast<unsigned*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,9 +184,14 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     }
     st.A1[0] = a1q[(q * 2 + 0) * 64 + lane];
     st.A1[1] = a1q[(q * 2 + 1) * 64 + lane];
+    // e4m3 conversions saturate at 448 instead of producing NaN (probed: tools/microbench/cvt_fp8_bf16_probe.hip)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
     st.one = 0x7F7F7F7Fu;
-    st.sat = 448.f;
-    asm volatile("" : "+v"(st.one), "+v"(st.sat));
+    st.scb = scale_b_e8m0 * 0x01010101u;
+    st.sc9 = 0.001953125f;
+    asm volatile("" : "+v"(st.one), "+v"(st.scb), "+v"(st.sc9));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st.T[k] = 0u;
 #pragma unroll
     for (int ot = 0; ot < 5; ++ot) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + 16 * ot + 4 * g);
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
         sch_wait_lds(st);
         sch_conv1_mfma<0, 0, 0>(st); sch_conv1_mfma<0, 0, 1>(st);
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(st.X[0]), "+v"(st.X[1]));
-        [&]<int... N>(std::integer_sequence<int, N...>) { (f8_relu<N>(st), ...); }(std::make_integer_sequence<int, 32>{});
+        [&]<int... K>(std::integer_sequence<int, K...>) { (f8_pkb<K>(st), ...); }(std::make_integer_sequence<int, 16>{});
         [&]<int... K>(std::integer_sequence<int, K...>) { (f8_cvt<0, K>(st), ...); }(std::make_integer_sequence<int, 16>{});
         asm volatile("s_nop 1");
 
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
             if (rng < 10) {      // finish of output S+13; the accumulators of S+14, S+15 are dropped
                 FinOut fo;
                 sch_wait_lds(st);
-                sch_fin_all(st, fo);
+                sch_fin_all_clamp(st, fo);
                 sch_store<0>(fo, fbase, vt, q, st.gs);
                 sch_store<1>(fo, fbase, vt, q, st.gs);
                 asm volatile("s_nop 7\n\ts_nop 7" ::"a"(acc[0][0]), "a"(acc[1][0]), "a"(acc[2][0]));
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
         auto finish_store = [&](int w) {
             FinOut fo;
             sch_wait_lds(st);
-            sch_fin_all(st, fo);
+            sch_fin_all_clamp(st, fo);
             sch_store<0>(fo, fbase, w, q, st.gs);
             sch_store<1>(fo, fbase, w, q, st.gs);
         };
@@ -344,9 +362,12 @@ int vtcnn2_fp8_pack(mdc_model* m) {
     if (!(w2max > 0.f) || !(c1bound > 0.f)) { set_error("fp8: degenerate weights (all zero)"); return MDC_EINVAL; }
     const int sw = (int)std::floor(std::log2(224.f / w2max));      // a factor 2 of head-room below 448
     const int sa = (int)std::floor(std::log2(224.f / c1bound));
-    const float fsw = std::ldexp(1.f, sw), fsa = std::ldexp(1.f, sa);
-    m->fp8_feat_scale_log2 = sa + sw;
-    m->feat_scale_log2 = sa + sw;
+    const float fsw = std::ldexp(1.f, sw), fsa = std::ldexp(1.f, sa - 9);      // conv1 operands: the e4m3 range sits in [0, 0.875] (see the header)
+    // the MFMA's E8M0 block scale of B takes the accumulators from 2^(sa+sw) to 2^-kFeatShift times the true values
+    const int e8 = 127 - (sa + sw + kFeatShift);
+    if (e8 < 1 || e8 > 254) { set_error("fp8: weight / input scales out of the block-scale range (sa %d, sw %d)", sa, sw); return MDC_EINVAL; }
+    m->fp8_feat_scale_log2 = e8;      // (kept under its old name: the E8M0 byte the conv kernel is launched with)
+    m->feat_scale_log2 = -kFeatShift;
 
     std::vector<unsigned char> wq((size_t)4 * kF8Frags * 64 * 32);
     for (int q = 0; q < 4; ++q)
@@ -379,11 +400,11 @@ int vtcnn2_fp8_pack(mdc_model* m) {
             }
     if ((rc = upload(m, 1, a1.data(), a1.size() * 2))) return rc;
     std::vector<float> b2s(kC2);
-    for (int o = 0; o < kC2; ++o) b2s[o] = m->hb[1][o] * fsa * fsw;
+    for (int o = 0; o < kC2; ++o) b2s[o] = std::ldexp(m->hb[1][o], -kFeatShift);
     if ((rc = upload(m, 2, b2s.data(), b2s.size() * sizeof(float)))) return rc;
-    // dense1: as the bf16 mode's, divided by the feature scale (exact: a power of two)
+    // dense1: exactly the bf16 mode's (its features carry the same 2^-kFeatShift)
     const float* w1 = m->hk[2].data();
-    const float inv = std::ldexp(1.f, -(sa + sw));
+    const float inv = std::ldexp(1.f, kFeatShift);
     std::vector<unsigned short> w1t((size_t)kHid * kFeat);
     for (int w = 0; w < kW2; ++w)
         for (int o = 0; o < kC2; ++o) {
@@ -401,7 +422,8 @@ int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, h
     MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<U, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
     hipLaunchKernelGGL((vt_conv_fp8_kernel<U, R>), GRID, dim3(256), kSchedLds, s, x, (long)n, \
                        static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]), \
-                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2 > 0 ? hop2 : 256L, scale); } while (0)
+                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2 > 0 ? hop2 : 256L, scale, \
+                       (unsigned)m->fp8_feat_scale_log2); } while (0)
     // hop2 > 0: raw uint8 I/Q straight into the staging.  Small batches: the position-range form (results identical)
     if (n <= kConvRangeFrames) {
         if (hop2 > 0) MDC_LAUNCH_F8(true, true, dim3((unsigned)ngroups, 11));
