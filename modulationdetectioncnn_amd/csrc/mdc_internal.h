@@ -36,6 +36,16 @@ constexpr int kW2 = 132;     // conv2 output width
 constexpr int kFeat = kC2 * kW2;   // 10560
 constexpr int kHid = 256;    // dense1 units
 
+// Feature row of the 16-bit modes (bf16 features; round 3): output positions in PAIRS of 160 elements --
+//   [64 channels of the even position][64 channels of the odd position][channels 64..79, each as (even, odd)]
+// so that the conv kernels' finishing lanes, which own ONE channel of the fifth output tile per position, store one
+// dword per pair of positions instead of one 2-byte store per position (a global_store_short costs a 16-cycle MFMA gap
+// 16 cycles, a dword store 4: tools/microbench/mfma_gap.hip).  The order of K is dense1's to choose: its weight rows
+// are permuted with the same function at pack time; the conv / flat taps un-permute.  (f32 features: [w][o], unchanged.)
+__host__ __device__ constexpr int feat16_index(int w, int o) {
+    return (w >> 1) * (2 * kC2) + (o < 64 ? (w & 1) * 64 + o : 128 + 2 * (o - 64) + (w & 1));
+}
+
 // 8 raw bytes from an address that is only 2-byte aligned (a window of a uint8 I/Q capture at an arbitrary hop):
 // gfx950 global loads take unaligned addresses, and hipcc emits ONE global_load_dwordx2 for this
 __device__ __forceinline__ uint2 load8_unaligned(const unsigned char* p) {

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void vt_dense1_f32_small_kernel(const float* __
     }
 }
 
-// feat[f][w][o] (f32 or bf16) -> reference layout (80,132) channels_first, f32   ('conv'/'flat' taps)
+// feat[f][w][o] (f32) / feat[f][feat16_index(w, o)] (bf16) -> reference layout (80,132) channels_first, f32   ('conv'/'flat' taps)
 template <typename T>
 __global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* __restrict__ out, float unscale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,9 +308,12 @@ __global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* _
     const long f = i / kFeat;
     const int r = (int)(i % kFeat);
     const int o = r / kW2, w = r % kW2;
-    const T v = feat[(f * kW2 + w) * kC2 + o];
-    if constexpr (sizeof(T) == 2) out[i] = __uint_as_float(((unsigned)v) << 16) * unscale;      // unscale = 1 or a power of two: exact
-    else out[i] = v;
+    if constexpr (sizeof(T) == 2) {      // 16-bit modes: positions in pairs (feat16_index), values times a power of two
+        const T v = feat[f * kFeat + feat16_index(w, o)];
+        out[i] = __uint_as_float(((unsigned)v) << 16) * unscale;      // exact
+    } else {
+        out[i] = feat[(f * kW2 + w) * kC2 + o];
+    }
 }
 
 }  // namespace

@@ -179,11 +179,11 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_kernel(const float* __res
             const f32x4 bq = *reinterpret_cast<const f32x4*>(bq_lds);
             o[0] = pack2relu(s[0] + bq[0], s[1] + bq[1]);
             o[1] = pack2relu(s[2] + bq[2], s[3] + bq[3]);
-            unsigned short* dst = fbase + (long)w * kC2;
             const float t = ((rc[0] + rc[1]) + (rc[2] + rc[3])) + *b4_lds;
             const unsigned short t16 = (unsigned short)pack2relu(t, 0.f);
-            *reinterpret_cast<u32x2*>(dst + 16 * q) = o;
-            dst[64 + q] = t16;
+            unsigned short* frow = fbase - 4 * g;      // (fbase carries the lane's 4-channel offset of the old [w][o] rows)
+            *reinterpret_cast<u32x2*>(frow + feat16_index(w, 16 * q + 4 * g)) = o;
+            frow[feat16_index(w, 64 + 4 * g + q)] = t16;
         };
 #define MDC_SB() __builtin_amdgcn_sched_barrier(0)
         // One position step v (outputs: a0 = v+2 fresh, a1 = v+1, a2 = v completes).  TAP-MAJOR order:
@@ -332,7 +332,7 @@ int vtcnn2_bf16_pack(mdc_model* m) {
         for (int o = 0; o < kC2; ++o) {
             const float* src = w1 + (size_t)(o * kW2 + w) * kHid;
             // tile-contiguous: [k-tile of 64][hidden unit][64], so a K-tile of the GEMM's B operand is one 32 KiB block
-            const int kk = w * kC2 + o;
+            const int kk = feat16_index(w, o);      // the K order the conv kernels store their features in
             for (int nn = 0; nn < kHid; ++nn) w1t[((size_t)(kk >> 6) * kHid + nn) * 64 + (kk & 63)] = f2bf(std::ldexp(src[nn], kFeatShift));
         }
     if ((rc = upload(m, 3, w1t.data(), w1t.size() * 2))) return rc;

@@ -74,6 +74,7 @@ struct SchedState {
     f32x16 X[2];              // conv1 results [channel block]
     f32x4 rp[4];
     float rc[4];
+    float tprev;              // fifth-tile value of the last EVEN output position (waits for its odd neighbour: one dword store per pair)
     u32x4 L0[3];              // conv1 operand words, entries (2c, 2c+1) of chunk c = position>>2, slot c%3
     u32x4 L1;                 // entries (2c+1, 2c+2)
     unsigned cb[4];           // B operand dwords of an odd position (v_alignbit results)
@@ -133,10 +134,11 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     const unsigned load_addr = st.im_addr + ((v >> 2) * 16 + (kLoadEven ? 16 : 24));      // 8 bytes per entry
     FinTmp ft;
     FinOut fo;
-#define FIN(K) do { if (!FIRST && kFin) sch_fin_clamp<K>(st, ft, fo); } while (0)
+    constexpr int OP = (V12 + 1) & 1;      // parity of the output position v - 1 this step finishes (12 is even)
+#define FIN(K) do { if (!FIRST && kFin) sch_fin_clamp<K, OP>(st, ft, fo); } while (0)
 #define PREP(I) do { if (!LAST && kC1 && ABL != 11) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST && kC1) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
-#define ST(W) do { if (!FIRST && kFin) { if (ABL == 7) asm volatile("" ::"v"(fo.o0), "v"(fo.o1), "v"(fo.tt)); else if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
+#define ST(W) do { if (!FIRST && kFin && (W == 0 || OP == 1)) { if (ABL == 7) { if (W == 0) asm volatile("" ::"v"(fo.o0), "v"(fo.o1)); else asm volatile("" ::"v"(fo.tt)); } else if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
 #define WR(OT) do { if (kExch && ABL != 8) sch_part_write<PAR, OT>(st, a2[OT]); } while (0)
 #define PK(N) do { if (!LAST && kC1 && ABL != 10) sch_packop<PN, N>(st); } while (0)
 #define RD(R) do { if (kExch && ABL != 9) sch_red_load1<PAR, R>(st); } while (0)
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
     for (int s = 0; s < 3; ++s) st.L0[s] = u32x4{0u, 0u, 0u, 0u};
     st.L1 = u32x4{0u, 0u, 0u, 0u};
     st.cb[0] = st.cb[1] = st.cb[2] = st.cb[3] = 0u;
+    st.tprev = 0.f;
 
     // LDS init: zero padding entries; the second word of every entry of the upper-k-half lanes (32..63) is the
     // constant (1,1) that meets the conv1 bias
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
             if (rng < 10) {      // finish of output S+13; the accumulators of S+14, S+15 are dropped
                 FinOut fo;
                 sch_wait_lds(st);
-                sch_fin_all_clamp(st, fo);
+                sch_fin_all_clamp<1>(st, fo);      // S + 13 is odd: the pair (S + 12, S + 13)
                 sch_store<0>(fo, fbase, vt, q, st.gs);
                 sch_store<1>(fo, fbase, vt, q, st.gs);
                 asm volatile("s_nop 7\n\ts_nop 7" ::"a"(acc[0][0]), "a"(acc[1][0]), "a"(acc[2][0]));      // in-flight MFMA results land before the registers die
@@ -375,27 +378,29 @@ __global__ __launch_bounds__(256, 1) void vt_conv_bf16_sched_kernel(const float*
         sch_step<9, false, true, ABL, RANGE>(st, 129, q, fbase, acc, wlo);
         // tail: finish 129, then outputs 130 and 131 (complete as they are: only zero padding beyond).
         // step 129 (v%3 == 0) left output 130 in acc[1] and output 131 in acc[2].
-        auto finish_store = [&](int w) {
+        auto finish_store = [&](auto odd, int w) {
             FinOut fo;
             sch_wait_lds(st);
-            sch_fin_all_clamp(st, fo);
+            sch_fin_all_clamp<decltype(odd)::value>(st, fo);
             sch_store<0>(fo, fbase, w, q, st.gs);
-            sch_store<1>(fo, fbase, w, q, st.gs);
+            if constexpr (decltype(odd)::value) sch_store<1>(fo, fbase, w, q, st.gs);
         };
-        finish_store(129);
+        using Even = std::integral_constant<int, 0>;
+        using Odd = std::integral_constant<int, 1>;
+        finish_store(Odd{}, 129);
         asm volatile("s_nop 7\n\ts_nop 7");       // last tap-1/tap-0 MFMAs -> ds_write of their accumulators
         sch_part_write<0, 0>(st, acc[1][0]); sch_part_write<0, 1>(st, acc[1][1]); sch_part_write<0, 2>(st, acc[1][2]);
         sch_part_write<0, 3>(st, acc[1][3]); sch_part_write<0, 4>(st, acc[1][4]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         sch_red_load<0>(st);
         asm volatile("" ::"a"(acc[1][0]), "a"(acc[1][1]), "a"(acc[1][2]), "a"(acc[1][3]), "a"(acc[1][4]));
-        finish_store(130);
+        finish_store(Even{}, 130);
         sch_part_write<1, 0>(st, acc[2][0]); sch_part_write<1, 1>(st, acc[2][1]); sch_part_write<1, 2>(st, acc[2][2]);
         sch_part_write<1, 3>(st, acc[2][3]); sch_part_write<1, 4>(st, acc[2][4]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         sch_red_load<1>(st);
         asm volatile("" ::"a"(acc[2][0]), "a"(acc[2][1]), "a"(acc[2][2]), "a"(acc[2][3]), "a"(acc[2][4]));
-        finish_store(131);
+        finish_store(Odd{}, 131);
         __syncthreads();      // next group's image is complete; partial buffers are free again
     }
 }

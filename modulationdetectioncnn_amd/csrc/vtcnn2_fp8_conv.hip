@@ -57,6 +57,7 @@ struct Fp8State {
     unsigned T[16];           // ReLU'd conv1 results as packed bf16 pairs
     f32x4 rp[4];
     float rc[4];
+    float tprev;              // fifth-tile value of the last even output position (vtcnn2_sched_common.h, sch_fin_clamp)
     u32x4 L0[3];
     u32x4 L1;
     unsigned cb[4];
@@ -113,10 +114,11 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
     const unsigned load_addr = st.im_addr + ((v >> 2) * 16 + (kLoadEven ? 16 : 24));
     FinTmp ft;
     FinOut fo;
-#define FIN(K) do { if (!FIRST) sch_fin_clamp<K>(st, ft, fo); } while (0)
+    constexpr int OP = (V12 + 1) & 1;      // parity of the output position v - 1 this step finishes
+#define FIN(K) do { if (!FIRST) sch_fin_clamp<K, OP>(st, ft, fo); } while (0)
 #define PREP(I) do { if (!LAST) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
-#define ST(W) do { if (!FIRST) { if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
+#define ST(W) do { if (!FIRST && (W == 0 || OP == 1)) { if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
 #define WR(OT) sch_part_write<PAR, OT>(st, a2[OT])
 #define PKB(K) do { if (!LAST) f8_pkb<K>(st); } while (0)
 #define CV(K) do { if (!LAST) f8_cvt<PN, K>(st); } while (0)
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     for (int s = 0; s < 3; ++s) st.L0[s] = u32x4{0u, 0u, 0u, 0u};
     st.L1 = u32x4{0u, 0u, 0u, 0u};
     st.cb[0] = st.cb[1] = st.cb[2] = st.cb[3] = 0u;
+    st.tprev = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) st.Bf[0][d] = st.Bf[1][d] = 0u;
 
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
             if (rng < 10) {      // finish of output S+13; the accumulators of S+14, S+15 are dropped
                 FinOut fo;
                 sch_wait_lds(st);
-                sch_fin_all_clamp(st, fo);
+                sch_fin_all_clamp<1>(st, fo);      // S + 13 is odd: the pair (S + 12, S + 13)
                 sch_store<0>(fo, fbase, vt, q, st.gs);
                 sch_store<1>(fo, fbase, vt, q, st.gs);
                 asm volatile("s_nop 7\n\ts_nop 7" ::"a"(acc[0][0]), "a"(acc[1][0]), "a"(acc[2][0]));
@@ -299,27 +302,29 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
         f8_step<9, false, true, RANGE>(st, 129, q, fbase, acc, wlo);
         // tail: finish 129, then outputs 130 and 131 (complete as they are: only zero padding beyond).
         // step 129 (v%3 == 0) left output 130 in acc[1] and output 131 in acc[2].
-        auto finish_store = [&](int w) {
+        auto finish_store = [&](auto odd, int w) {
             FinOut fo;
             sch_wait_lds(st);
-            sch_fin_all_clamp(st, fo);
+            sch_fin_all_clamp<decltype(odd)::value>(st, fo);
             sch_store<0>(fo, fbase, w, q, st.gs);
-            sch_store<1>(fo, fbase, w, q, st.gs);
+            if constexpr (decltype(odd)::value) sch_store<1>(fo, fbase, w, q, st.gs);
         };
-        finish_store(129);
+        using Even = std::integral_constant<int, 0>;
+        using Odd = std::integral_constant<int, 1>;
+        finish_store(Odd{}, 129);
         asm volatile("s_nop 7\n\ts_nop 7");       // last tap-1/tap-0 MFMAs -> ds_write of their accumulators
         sch_part_write<0, 0>(st, acc[1][0]); sch_part_write<0, 1>(st, acc[1][1]); sch_part_write<0, 2>(st, acc[1][2]);
         sch_part_write<0, 3>(st, acc[1][3]); sch_part_write<0, 4>(st, acc[1][4]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         sch_red_load<0>(st);
         asm volatile("" ::"a"(acc[1][0]), "a"(acc[1][1]), "a"(acc[1][2]), "a"(acc[1][3]), "a"(acc[1][4]));
-        finish_store(130);
+        finish_store(Even{}, 130);
         sch_part_write<1, 0>(st, acc[2][0]); sch_part_write<1, 1>(st, acc[2][1]); sch_part_write<1, 2>(st, acc[2][2]);
         sch_part_write<1, 3>(st, acc[2][3]); sch_part_write<1, 4>(st, acc[2][4]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         sch_red_load<1>(st);
         asm volatile("" ::"a"(acc[2][0]), "a"(acc[2][1]), "a"(acc[2][2]), "a"(acc[2][3]), "a"(acc[2][4]));
-        finish_store(131);
+        finish_store(Odd{}, 131);
         __syncthreads();      // next group's image is complete; partial buffers are free again
     }
 }
@@ -409,7 +414,7 @@ int vtcnn2_fp8_pack(mdc_model* m) {
     for (int w = 0; w < kW2; ++w)
         for (int o = 0; o < kC2; ++o) {
             const float* srcw = w1 + (size_t)(o * kW2 + w) * kHid;
-            const int kk = w * kC2 + o;
+            const int kk = feat16_index(w, o);
             for (int nn = 0; nn < kHid; ++nn) w1t[((size_t)(kk >> 6) * kHid + nn) * 64 + (kk & 63)] = f2bf(srcw[nn] * inv);
         }
     return upload(m, 3, w1t.data(), w1t.size() * 2);

@@ -2,7 +2,7 @@
 // per-lane image of a 16-frame group and its staging, the conv1 operand reads and MFMA, the partial-sum exchange
 // and the one-VALU-at-a-time finish.  Each helper is ONE asm instruction (or a fixed short sequence) so that the
 // kernels' step functions can place it in a chosen MFMA gap.  S is the kernel's state struct; the members used
-// here are: A1, X, rp, rc, L0, L1, cb, wr_addr, rd_addr, rc_addr, im_addr.
+// here are: A1, X, rp, rc, L0, L1, cb, wr_addr, rd_addr, rc_addr, im_addr, tprev.
 #pragma once
 #include "vtcnn2_bf16_common.h"
 
@@ -80,9 +80,9 @@ __device__ __forceinline__ void sch_wait_lds(S& st) {
                    "+v"(st.rc[3]), "+v"(st.L0[0]), "+v"(st.L0[1]), "+v"(st.L0[2]), "+v"(st.L1)
                  :: "memory");
 }
-// finish of one output position, one VALU instruction per call (K = 0..20): sum of the 4 partials (the bias is
-// already in wave 0's), ReLU, bf16.  Plain v_add_f32: v_pk_add_f32 costs a whole MFMA gap.
-struct FinOut { unsigned o0, o1, tt; };
+// finish of one output position, one VALU instruction per call: sum of the 4 partials (the bias is already in wave
+// 0's), ReLU, bf16.  Plain v_add_f32: v_pk_add_f32 costs a whole MFMA gap.
+struct FinOut { unsigned o0, o1, tt; };      // tt: channel 64 + 4q + gs of the EVEN position (low half) and the odd one (high half)
 struct FinTmp { float s[4], u[4], a, b, t; };
 // kFeatShift: the bf16 mode keeps its conv1 activations and conv2 features multiplied by 2^-kFeatShift (round 3).  A power
 // of two costs nothing -- conv1's taps and bias and conv2's bias carry 2^-kFeatShift, dense1's weights 2^+kFeatShift, all
@@ -93,8 +93,10 @@ struct FinTmp { float s[4], u[4], a, b, t; };
 // they saturate (a NaN becomes 0).  19 fewer VALU per position step and wave (16 in conv1's pack, 3 in the finish).
 constexpr int kFeatShift = 32;
 
-// the clamp form of the finish (CLAMP = true: K = 0..17; values below 1, see kFeatShift) drops the three v_pk_max_i16
-template <int K, class S>
+// the clamp form of the finish (K = 0..17; values below 1, see kFeatShift) drops the three v_pk_max_i16.  ODD = parity of
+// the output position: the fifth tile's value of an even position waits in st.tprev (f32) for its odd neighbour and the
+// two are packed, clamped and stored together (feat16_index: one dword per pair) -- an even position has 17 instructions.
+template <int K, int ODD, class S>
 __device__ __forceinline__ void sch_fin_clamp(S& st, FinTmp& f, FinOut& out) {
     if constexpr (K < 4) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.s[K]) : "v"(st.rp[0][K]), "v"(st.rp[1][K]));
     else if constexpr (K < 8) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.u[K - 4]) : "v"(st.rp[2][K - 4]), "v"(st.rp[3][K - 4]));
@@ -103,44 +105,26 @@ __device__ __forceinline__ void sch_fin_clamp(S& st, FinTmp& f, FinOut& out) {
     else if constexpr (K == 13) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(out.o1) : "v"(f.s[2]), "v"(f.s[3]));
     else if constexpr (K == 14) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.a) : "v"(st.rc[0]), "v"(st.rc[1]));
     else if constexpr (K == 15) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.b) : "v"(st.rc[2]), "v"(st.rc[3]));
-    else if constexpr (K == 16) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.t) : "v"(f.a), "v"(f.b));
-    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1 clamp" : "=v"(out.tt) : "v"(f.t));
+    else if constexpr (K == 16) {
+        if constexpr (ODD) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.t) : "v"(f.a), "v"(f.b));
+        else asm volatile("v_add_f32 %0, %1, %2" : "=v"(st.tprev) : "v"(f.a), "v"(f.b));
+    } else if constexpr (ODD) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(out.tt) : "v"(st.tprev), "v"(f.t));
 }
-template <class S>
+template <int ODD, class S>
 __device__ __forceinline__ void sch_fin_all_clamp(S& st, FinOut& out) {
     FinTmp f;
-    [&]<int... K>(std::integer_sequence<int, K...>) { (sch_fin_clamp<K>(st, f, out), ...); }(std::make_integer_sequence<int, 18>{});
+    [&]<int... K>(std::integer_sequence<int, K...>) { (sch_fin_clamp<K, ODD>(st, f, out), ...); }(std::make_integer_sequence<int, 18>{});
 }
 
-template <int K, class S>
-__device__ __forceinline__ void sch_fin(S& st, FinTmp& f, FinOut& out) {
-    if constexpr (K < 4) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.s[K]) : "v"(st.rp[0][K]), "v"(st.rp[1][K]));
-    else if constexpr (K < 8) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.u[K - 4]) : "v"(st.rp[2][K - 4]), "v"(st.rp[3][K - 4]));
-    else if constexpr (K < 12) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f.s[K - 8]) : "v"(f.u[K - 8]));
-    else if constexpr (K == 12) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(out.o0) : "v"(f.s[0]), "v"(f.s[1]));
-    else if constexpr (K == 13) asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(out.o0));
-    else if constexpr (K == 14) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(out.o1) : "v"(f.s[2]), "v"(f.s[3]));
-    else if constexpr (K == 15) asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(out.o1));
-    else if constexpr (K == 16) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.a) : "v"(st.rc[0]), "v"(st.rc[1]));
-    else if constexpr (K == 17) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.b) : "v"(st.rc[2]), "v"(st.rc[3]));
-    else if constexpr (K == 18) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.t) : "v"(f.a), "v"(f.b));
-    else if constexpr (K == 19) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(out.tt) : "v"(f.t));
-    else asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(out.tt));
-}
-template <class S>
-__device__ __forceinline__ void sch_fin_all(S& st, FinOut& out) {
-    FinTmp f;
-    [&]<int... K>(std::integer_sequence<int, K...>) { (sch_fin<K>(st, f, out), ...); }(std::make_integer_sequence<int, 21>{});
-}
 // The finishing lane layout is TRANSPOSED with respect to the MFMA layout: lane L finishes frame L>>2, channel
-// chunk gs = L&3, so the four lanes of a quad write 32 (and 8) contiguous bytes of one frame's row.
-// Wave q stores channels [16q+4gs, +4) (WHICH = 0) and channel 64+4q+gs (WHICH = 1) of its lane's frame (row frow)
-// at output position w.
+// chunk gs = L&3, so the four lanes of a quad write 32 (and 16) contiguous bytes of one frame's row.
+// Wave q stores channels [16q+4gs, +4) of output position w (WHICH = 0: 8 bytes) and, after an ODD position only,
+// channel 64+4q+gs of positions w-1 and w (WHICH = 1: one dword) of its lane's frame (row frow); feat16_index layout.
 template <int WHICH>
 __device__ __forceinline__ void sch_store(const FinOut& fo, unsigned short* frow, int w, int q, int gs) {
-    unsigned short* dst = frow + (long)w * kC2;
-    if constexpr (WHICH == 0) *reinterpret_cast<u32x2*>(dst + 16 * q + 4 * gs) = u32x2{fo.o0, fo.o1};
-    else dst[64 + 4 * q + gs] = (unsigned short)fo.tt;
+    unsigned short* pair = frow + (long)(w >> 1) * (2 * kC2);
+    if constexpr (WHICH == 0) *reinterpret_cast<u32x2*>(pair + (w & 1) * 64 + 16 * q + 4 * gs) = u32x2{fo.o0, fo.o1};
+    else *reinterpret_cast<unsigned*>(pair + 128 + 2 * (4 * q + gs)) = fo.tt;
 }
 
 // staging of a quarter (k) of a 16-frame group into this kernel's image layout; see stage_load in the common header

@@ -4,7 +4,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1150 -- 'bash tools/collect_all.sh r02'
 # then here:  bash tools/collect_all.sh r02 summarize
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 if [ "$2" = "summarize" ]; then
     python3 tools/summarize_profiles.py $TAG > /dev/null
     python3 tools/summarize_dep_counters.py $TAG > /dev/null
@@ -13,6 +13,6 @@ if [ "$2" = "summarize" ]; then
     exit 0
 fi
 bash tools/collect_profiles.sh $TAG > gpurun_out/collect_${TAG}.log 2>&1
-bash tools/collect_dep_counters.sh >> gpurun_out/collect_${TAG}.log 2>&1
+bash tools/collect_dep_counters.sh $TAG >> gpurun_out/collect_${TAG}.log 2>&1
 python3 bench.py > gpurun_out/bench_${TAG}_final.json 2> gpurun_out/bench_${TAG}_final.err
 tail -c 300 gpurun_out/bench_${TAG}_final.json

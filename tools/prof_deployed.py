@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """rocprofv3 driver: a few forwards of the deployed F=3 / F=10 nets on 2^20 frames.
     prof_deployed.py [f32] [bf16] [f16] [fp8] [u8] [q612]     (default: f32 bf16 f16; u8 = the same dtypes on raw uint8 I/Q; q612 = the integer forward)
-MDC_DEP_F32_MFMA=1 in the environment selects the f32 variant with the dense layer on the f32 matrix pipe."""
+MDC_DEP_F32_MFMA=1 in the environment selects the f32 variant with the dense layer on the f32 matrix pipe (it lives in the
+alternates test build, libmdc_alt.so, which is then the library that is loaded)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +17,7 @@ for f in ("3convmodrecnets_CNN2_0.5.npz", "convmodrecnets_CNN2_0.5.npz"):
     for dt in ("f32", "bf16", "f16", "fp8"):
         if dt not in args:
             continue
-        m = VTCNN2.from_npz(os.path.join(g, f), device=0, dtype=dt)
+        m = VTCNN2.from_npz(os.path.join(g, f), device=0, dtype=dt, _lib_variant="alternates" if os.environ.get("MDC_DEP_F32_MFMA") == "1" else "product")
         for _ in range(3):
             m.forward_device(x)
             if iq is not None:
