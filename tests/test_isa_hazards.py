@@ -19,7 +19,7 @@ def test_sched_kernel_has_no_store_vs_mfma_hazard(inst):
     spec.loader.exec_module(lint)
     isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_sched.hip"), "vt_conv_bf16_sched_kernel" + inst)
     assert sum(1 for x in isa if x.startswith("v_mfma")) > 1000          # the kernel was found and is unrolled
-    assert sum(1 for x in isa if x.startswith("global_store")) >= 40
+    assert sum(1 for x in isa if x.startswith("global_store")) >= 30          # (one dwordx2 per step, one dword per odd step, the tails)
     assert lint.lint(isa) == []
 
 
