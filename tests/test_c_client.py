@@ -16,7 +16,7 @@ CFLAGS = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I",
 
 def test_header_is_plain_c99(tmp_path):
     tu = tmp_path / "only_header.c"
-    tu.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 2 ? 0 : 1; }\n')
+    tu.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 3 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(tu)], check=True)
 
 
