@@ -201,20 +201,20 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     // ---- T0: tap 0 (5 fresh).  gaps: last pack, hand-off, the 8 reads of partial(v), operand load (every 2nd step)
     sch_tap<PAR, 0, 0>(st, a0); PK(15);
     sch_tap<PAR, 0, 1>(st, a0);
-    sch_tap<PAR, 0, 2>(st, a0); HANDOFF();
-    sch_tap<PAR, 0, 3>(st, a0); RD(0);
-    sch_tap<PAR, 0, 4>(st, a0); RD(1);
-    sch_tap<PAR, 0, 5>(st, a0); RD(2);
-    sch_tap<PAR, 0, 6>(st, a0); RD(3);
-    sch_tap<PAR, 0, 7>(st, a0); RD(4);
-    sch_tap<PAR, 0, 8>(st, a0); RD(5);
-    sch_tap<PAR, 0, 9>(st, a0); RD(6);
-    sch_tap<PAR, 0, 10>(st, a0); RD(7);
-    sch_tap<PAR, 0, 11>(st, a0); LD();      // (behind the hand-off: its lgkmcnt(0) does not have to wait for this read)
-    sch_tap<PAR, 0, 12>(st, a0);
-    sch_tap<PAR, 0, 13>(st, a0);
-    sch_tap<PAR, 0, 14>(st, a0);
-    sch_tap<PAR, 0, 15>(st, a0);
+    sch_tap<PAR, 0, 2>(st, a0);
+    sch_tap<PAR, 0, 3>(st, a0);
+    sch_tap<PAR, 0, 4>(st, a0);
+    sch_tap<PAR, 0, 5>(st, a0);
+    sch_tap<PAR, 0, 6>(st, a0); HANDOFF();
+    sch_tap<PAR, 0, 7>(st, a0); RD(0);
+    sch_tap<PAR, 0, 8>(st, a0); RD(1);
+    sch_tap<PAR, 0, 9>(st, a0); RD(2);
+    sch_tap<PAR, 0, 10>(st, a0); RD(3);
+    sch_tap<PAR, 0, 11>(st, a0); RD(4);
+    sch_tap<PAR, 0, 12>(st, a0); RD(5);
+    sch_tap<PAR, 0, 13>(st, a0); RD(6);
+    sch_tap<PAR, 0, 14>(st, a0); RD(7);
+    sch_tap<PAR, 0, 15>(st, a0); LD();
     sch_tap<PAR, 0, 16>(st, a0);
     sch_tap<PAR, 0, 17>(st, a0);
     sch_tap<PAR, 0, 18>(st, a0);
