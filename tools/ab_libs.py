@@ -20,19 +20,25 @@ if sys.argv[1] != "current":
 import torch, hashlib
 from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames
 x = synthetic_frames(1 << 20, seed=2016, device="cuda:0")
+G = os.path.join(%r, "tests", "golden", "weights")
 for dt in sys.argv[2].split(","):
-    m = VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, device=0, dtype=dt)
+    if dt.startswith("dep"):      # dep3-f32, dep10-bf16, ...: the bundled deployed nets (per-kernel time = the whole forward)
+        net, dd = dt.split("-")
+        m = VTCNN2.from_npz(os.path.join(G, ("3" if net == "dep3" else "") + "convmodrecnets_CNN2_0.5.npz"), device=0, dtype=dd)
+    else:
+        m = VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, device=0, dtype=dt)
     CH = int(sys.argv[3])
     p, l, _ = m.forward_device(x, batch_size=CH)
     torch.cuda.synchronize()
     sha = hashlib.sha1(p.cpu().numpy().tobytes() + l.cpu().numpy().tobytes()).hexdigest()[:10]
     m.set_profiling(True)
-    for _ in range(8): m.forward_device(x, probs=p, labels=l, batch_size=CH)
+    REPS = 40 if dt.startswith("dep") else 8
+    for _ in range(REPS): m.forward_device(x, probs=p, labels=l, batch_size=CH)
     torch.cuda.synchronize()
-    prof = {k: v[0] / 8 for k, v in m.read_profile().items()}      # per 2^20 frames, however many launches that took
+    prof = {k: v[0] / REPS for k, v in m.read_profile().items()}      # per 2^20 frames, however many launches that took
     print("RES", dt, sha, " ".join(f"{k[7:]} {v:.3f}" for k, v in prof.items()), "sum %%.3f" %% sum(prof.values()), flush=True)
     del m
-''' % ROOT
+''' % (ROOT, ROOT)
 for rnd in range(rounds):
     for name, lib in (("prev   ", other), ("current", "current")):
         r = subprocess.run([sys.executable, "-c", CHILD, lib, dtypes, str(chunk)], capture_output=True, text=True)
