@@ -36,6 +36,8 @@ def counters(d, kern):
 os.makedirs(P, exist_ok=True)
 for d in sorted(glob.glob(os.path.join(G, "prof_*"))):
     tag = os.path.basename(d)[5:]
+    if tag[:1] == "r" and tag[1:3].isdigit() and not tag.startswith(rnd):
+        continue      # another round's scratch directory still lying in gpurun_out/
     for f in sorted(glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:      # newest run only
         shutil.copy(f, os.path.join(P, (tag if tag.startswith(rnd) else f"{rnd}_{tag}") + "_kernel_stats.csv"))
 
