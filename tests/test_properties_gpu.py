@@ -75,3 +75,19 @@ def test_host_driver_equals_the_device_path(key, n, chunk):
     p, l, _ = m.forward_device(torch.from_numpy(x).cuda())
     np.testing.assert_array_equal(probs, p.cpu().numpy())
     np.testing.assert_array_equal(labels, l.cpu().numpy())
+
+
+@settings(**{**_S, "max_examples": _S["max_examples"] if _N else 25})
+@given(st.sampled_from(["vtcnn2-bf16", "vtcnn2-fp8"]), st.integers(2049, 9000), st.data())
+def test_fused_head_batches_equal_any_chunking_across_the_small_batch_threshold(key, n, data):
+    """Round 3: above 2,048 frames a 16-bit VT-CNN2 call runs dense2 + softmax + argmax inside the dense1 GEMM's epilogue;
+    at or below it the small-batch dense1 forms write the hidden layer and the head is its own launch.  A batch cut into
+    calls on either side of that threshold -- ragged last tiles included -- must give the same bits as one call."""
+    m = _model(key)
+    x = synthetic_frames(n, seed=n, device="cuda")
+    p, l, _ = m.forward_device(x, batch_size=n)                       # one call: fused head
+    bs = data.draw(st.sampled_from([17, 256, 1000, 2048, 2049, 2305, 4096]))
+    p2, l2, _ = m.forward_device(x, batch_size=bs)
+    assert torch.equal(p, p2) and torch.equal(l, l2), (n, bs)
+    p3, l3, _ = m.forward_device(x, tap="dense")                      # the unfused batch path (a logit tap keeps the head separate)
+    assert torch.equal(p, p3) and torch.equal(l, l3)
