@@ -59,6 +59,9 @@ enum {
 
 /* Arithmetic type of the matrix products (accumulation is always f32).  MDC_BF16: MDC_KIND_VTCNN2 (both convs'
  * and dense1's operands) and MDC_KIND_DEPLOYED (the dense layer's operands; the conv stays f32; no layer taps).
+ * MDC_KIND_VTCNN2 in the 16-bit modes keeps its activations and features multiplied by 2^-32 internally (an exact
+ * power of two; the ReLU then rides in the bf16 conversion's clamp bit): conv1 / conv2 activations of 2^32 (4.3e9)
+ * and beyond saturate, those below 2^-94 flush to zero -- I/Q samples of order 1e-2 sit in the middle of that range.
  * MDC_F16: MDC_KIND_DEPLOYED only -- as MDC_BF16 there, with IEEE f16 operands and the conv itself in packed f16
  * (11 significant bits instead of 8, but conv outputs must stay below 65,504).
  * MDC_FP8: MDC_KIND_VTCNN2 -- conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16) -- and
