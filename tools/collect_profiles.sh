@@ -29,6 +29,11 @@ for W in "vtcnn2-c11-fp8-n2^20:fp8" "vtcnn2-c3-f32-n65536:f32"; do
   rm -rf $R/gpurun_out/pmc_fetch_vt$SFX $R/gpurun_out/pmc_write_vt$SFX
   rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt$SFX -- $BW > $R/gpurun_out/pmc_fetch_vt$SFX.log 2>&1
   rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_vt$SFX -- $BW > $R/gpurun_out/pmc_write_vt$SFX.log 2>&1
+  if [ "$SFX" = "fp8" ]; then      # MFMA-pipe and LDS / wait counters of the fp8 conv kernel too (BASELINE configs[4])
+    rm -rf $R/gpurun_out/pmc_mfma_vtfp8 $R/gpurun_out/pmc_lds_vtfp8
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA $P -d $R/gpurun_out/pmc_mfma_vtfp8 -- $BW > $R/gpurun_out/pmc_mfma_vtfp8.log 2>&1
+    rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES $P -d $R/gpurun_out/pmc_lds_vtfp8 -- $BW > $R/gpurun_out/pmc_lds_vtfp8.log 2>&1
+  fi
 done
 echo "vtcnn2 counters done"
 fi

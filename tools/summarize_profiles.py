@@ -86,16 +86,18 @@ print(json.dumps(out, indent=1))
 # MFMA-pipe utilisation of the bf16 VT-CNN2 kernels (own --pmc pass): busy = SQ_VALU_MFMA_BUSY_CYCLES /
 # (4 SIMDs x 256 CUs x cycles), cycles = GRBM_GUI_ACTIVE summed over the 8 XCDs / 8.
 mf = {}
-for key, kern in (("mdc_vt_conv/bf16", "vt_conv_bf16"), ("mdc_vt_dense1/bf16", "vt_dense1_bf16")):
-    c = counters("pmc_mfma_vt", kern)
+SETS = (("mdc_vt_conv/bf16", "vt_conv_bf16", "vt"), ("mdc_vt_dense1/bf16", "vt_dense1_bf16", "vt"),
+        ("mdc_vt_conv/fp8", "vt_conv_fp8_kernel", "vtfp8"), ("mdc_vt_dense1/fp8", "vt_dense1_bf16", "vtfp8"))
+for key, kern, sfx in SETS:
+    c = counters("pmc_mfma_" + sfx, kern)
     if not c:
         continue
     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
     mf[key] = {"GRBM_GUI_ACTIVE_sum": c["GRBM_GUI_ACTIVE"], "cycles_per_launch": cyc, "SQ_INSTS_MFMA": c["SQ_INSTS_MFMA"],
                "SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"],
                "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cyc)}
-for key, kern in (("mdc_vt_conv/bf16", "vt_conv_bf16"), ("mdc_vt_dense1/bf16", "vt_dense1_bf16")):
-    c = counters("pmc_lds_vt", kern)
+for key, kern, sfx in SETS:
+    c = counters("pmc_lds_" + sfx, kern)
     if c and key in mf:
         mf[key].update({"SQ_LDS_BANK_CONFLICT": c.get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": c.get("SQ_LDS_IDX_ACTIVE"),
                         "lds_conflict_frac": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
