@@ -301,6 +301,23 @@ def f32_mfma(monkeypatch):
     monkeypatch.setattr(sys.modules[__name__], "_VARIANT", "alternates")
 
 
+@pytest.mark.parametrize("ring", [2, 3, 4, 6, 8])
+def test_lds_dma_ring_form_of_the_t1_kernel_is_bit_identical(monkeypatch, ring):
+    """Round 3: T1's f32 kernel fed through a per-wave LDS-DMA ring (asm-issued copies, counted vmcnt)
+    instead of direct loads -- measured slower at every depth, so it lives in the alternates build; its
+    results must be the product's bits: full blocks through the ring, the ragged tail through the tail form, more blocks
+    than waves and fewer."""
+    monkeypatch.setenv("MDC_DEP_RING", str(ring))
+    name = "3convmodrecnets_CNN2_0.5"
+    ref = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"))
+    alt = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), _lib_variant="alternates")
+    for n in (64, 65, 1000, 64 * 2049 + 7, 1 << 19):
+        x = synthetic_frames(n, seed=n, device="cuda")
+        pa, la, _ = alt.forward_device(x)
+        pr, lr, _ = ref.forward_device(x)
+        assert torch.equal(pa, pr) and torch.equal(la, lr), (ring, n)
+
+
 def test_the_alternates_build_runs_the_product_kernels_unless_told_otherwise():
     """libmdc_alt.so without any of its environment variables is the product: bit-identical results."""
     x = synthetic_frames(1000, seed=4)
