@@ -76,6 +76,17 @@ struct Bf16Geom {
 using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
+// bf16 mode: ReLU + pack of two conv outputs in ONE v_cvt_pk_bf16_f32 with the VOP3 clamp bit (round 3; the conversion then
+// clamps to [0, 1]: tools/microbench/cvt_bf16_clamp_probe.hip).  The conv taps and bias carry 2^-kDepShift and the dense
+// weights 2^+kDepShift -- exact powers of two, every product and f32 sum the same bits as with v_cvt_pk_bf16_f32 +
+// v_pk_max_i16 -- so the values stay below 1 unless a conv output exceeds 2^32.
+constexpr int kDepShift = 32;
+__device__ __forceinline__ unsigned pack2clamp(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // four f32 -> four e4m3 in one dword (byte i = value i), ReLU and saturation at the e4m3 maximum by one v_med3_f32 each
 __device__ __forceinline__ unsigned pack4relu_fp8(float a, float b, float c, float d) {
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, 0.f, 448.f), __builtin_amdgcn_fmed3f(b, 0.f, 448.f), 0, false);
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                         for (int i = 0; i < G::kUnitVals / 4; ++i) pk[i] = pack4relu_fp8(vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < G::kUnitVals / 2; ++i) pk[i] = pack2relu(vals[2 * i], vals[2 * i + 1]);
+                        for (int i = 0; i < G::kUnitVals / 2; ++i) pk[i] = pack2clamp(vals[2 * i], vals[2 * i + 1]);
                     }
                 } else {
                     _Float16 hv[G::kUnitVals];
@@ -338,8 +349,8 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                     const unsigned hi = pack4relu_fp8(ev[8 * mm + 4], ev[8 * mm + 5], ev[8 * mm + 6], ev[8 * mm + 7]);
                     acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(((unsigned long)a.y << 32) | a.x), (long)(((unsigned long)hi << 32) | lo), acc[m & 1], 0, 0, 0);
                 } else {
-                    const u32x4 b = u32x4{pack2relu(ev[8 * mm + 0], ev[8 * mm + 1]), pack2relu(ev[8 * mm + 2], ev[8 * mm + 3]),
-                                          pack2relu(ev[8 * mm + 4], ev[8 * mm + 5]), pack2relu(ev[8 * mm + 6], ev[8 * mm + 7])};
+                    const u32x4 b = u32x4{pack2clamp(ev[8 * mm + 0], ev[8 * mm + 1]), pack2clamp(ev[8 * mm + 2], ev[8 * mm + 3]),
+                                          pack2clamp(ev[8 * mm + 4], ev[8 * mm + 5]), pack2clamp(ev[8 * mm + 6], ev[8 * mm + 7])};
                     acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m & 1], 0, 0, 0);
                 }
             }
@@ -433,7 +444,7 @@ void pack_atab(const mdc_model* m, std::vector<unsigned short>& tab, float wscal
                     }
                     const size_t entry = (((size_t)mi * 4 + kg) * kC + c) * 8;      // in 16-bit units
                     if (m->dtype == MDC_FP8) reinterpret_cast<unsigned char*>(&tab[entry])[i] = f2e4m3_sat(w * wscale);
-                    else tab[entry + i] = m->dtype == MDC_F16 ? f2h(w) : f2bf(w);
+                    else tab[entry + i] = m->dtype == MDC_F16 ? f2h(w) : f2bf(w * wscale);      // bf16: wscale = 2^kDepShift (exact)
                 }
 }
 
@@ -464,6 +475,21 @@ int deployed_bf16_pack(mdc_model* m) {
         const int rc = upload(m, 4, head.data(), head.size() * sizeof(float));
         if (rc != MDC_OK) return rc;
     }
+    if (m->dtype == MDC_BF16) {      // conv taps and bias x 2^-kDepShift, dense weights x 2^+kDepShift (pack2clamp); slot 4 like the fp8 head
+        const float* ck = m->hk[0].data();
+        const float sc = std::ldexp(1.f, -kDepShift);
+        wscale = std::ldexp(1.f, kDepShift);
+        std::vector<float> head(64, 0.f);
+        for (int f = 0; f < F; ++f) {
+            head[3 * f + 0] = ck[f] * sc;
+            head[3 * f + 1] = ck[F + f] * sc;
+            head[3 * f + 2] = m->hb[0][f] * sc;
+        }
+        for (int c = 0; c < kC; ++c) head[3 * F + c] = m->hb[1][c];
+        head[3 * F + kC] = 1.f;
+        const int rc = upload(m, 4, head.data(), head.size() * sizeof(float));
+        if (rc != MDC_OK) return rc;
+    }
     std::vector<unsigned short> tab;
     if (F == 3) pack_atab<3>(m, tab, wscale);
     else pack_atab<10>(m, tab, wscale);
@@ -473,7 +499,7 @@ int deployed_bf16_pack(mdc_model* m) {
 template <int F, bool U8>
 static int launch_bf16(const mdc_model* m, const void* x, int64_t n, float scale, float* probs, int32_t* labels, hipStream_t s, long hop2 = 256) {
     using G = Bf16Geom<F>;
-    const float* wp = static_cast<const float*>(m->d_pack[m->dtype == MDC_FP8 ? 4 : 0]);
+    const float* wp = static_cast<const float*>(m->d_pack[(m->dtype == MDC_FP8 || m->dtype == MDC_BF16) ? 4 : 0]);      // scaled heads (slot 4)
     const uint4* atab = static_cast<const uint4*>(m->d_pack[2]);
     const float* xf = static_cast<const float*>(x);
     const long ngroups = (n + 15) / 16;
