@@ -86,14 +86,10 @@ typedef struct mdc_topology {
     int32_t reserved[4]; /* [0]: option bits MDC_OPT_* (0 = defaults); [1..3] must be 0      */
 } mdc_topology;
 
-/* Option bits (mdc_topology.reserved[0]; validated by mdc_create, fixed for the model's life).
- * MDC_OPT_KERAS_CONV_ORDER  deployed 10-filter net at f32: evaluate the conv as Keras does (two fmas + max per
- *                           output) instead of the re-associated "pivot" form mdc_finalize otherwise chooses when
- *                           every second tap is non-zero (one fma + one v_med3, sign/scale folded into the dense
- *                           weights; same function within 2e-6 of the probabilities, 7-9 % faster).  The 3-filter
- *                           net -- the one whose output is pinned to Keras' recorded vector -- always runs Keras' order. */
-#define MDC_OPT_KERAS_CONV_ORDER 1
-#define MDC_OPT_ALL 1
+/* Option bits (mdc_topology.reserved[0]; validated by mdc_create, fixed for the model's life).  None is defined: every
+ * kernel evaluates the layers in Keras' operation order (round 2's re-associated conv of the 10-filter net and the bit
+ * that switched it off are gone: the ReLU now rides in the fma's clamp bit, which is faster AND exact). */
+#define MDC_OPT_ALL 0
 
 typedef struct mdc_model mdc_model;   /* opaque, owned by the library */
 

@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "libmdc.so")
 # "alternates" = the -DMDC_ALTERNATES test build (build.py): the product kernels plus the measured-slower alternates the
 # GPU suite holds them against.  Tests ask for it by name; nothing in the package does.
 LIB_PATHS = {"product": LIB_PATH, "alternates": os.path.join(_HERE, "libmdc_alt.so")}
-OPT_KERAS_CONV_ORDER = 1
 
 KIND_DEPLOYED, KIND_VTCNN2, KIND_CNNPY = 1, 2, 3
 F32, BF16, FP8, F16 = 0, 1, 2, 3

@@ -172,12 +172,14 @@ __device__ __forceinline__ float rows_sum(float m) {       // sum over the four 
 // mdc_iq_u8_to_frames followed by mdc_forward -- with 256 instead of 1,024 B of HBM input per frame.  Window f of the
 // capture starts at byte f * hop2 (hop2 = 256: disjoint frames; smaller: overlapping windows of a live stream, whose
 // bytes are then fetched from HBM once and re-read from cache); only 2-byte alignment of a window is assumed.
-// PIV = true (F = 10, VALU-bound; chosen at pack time when the weights allow it, deployed_pack): the pivot form of the conv.  With p = K1[f] != 0, r = K0/K1, beta = b/K1:
-//   relu(b + K0 x[w-1] + K1 x[w]) = |p| * relu(sign(p) * (t + beta)),  t = fma(r, x[w-1], x[w]),
-//   and for sign(p) > 0  relu(t + beta) = max(t, -beta) + beta,  for sign(p) < 0  relu(-(t + beta)) = -(min(t, -beta) + beta):
-// ONE fma and ONE v_med3_f32(t, lo, hi) per conv output -- (lo, hi) = (-beta, +inf) or (-inf, -beta) -- instead of two
-// fmas and a max; sign(p)*|p| is folded into the dense weights and sum(D' * beta) into the dense bias on the host (in
-// f64, deployed_pack).  The table has the layout of the plain one: head triples (r, lo, hi), bias', weights D'.
+// ReLU rides in the clamp bit of the conv's second fma (round 3): the fast kernel's table carries the conv taps and bias
+// times 2^-32 and the dense weights times 2^+32 -- exact powers of two: every product and every f32 sum is the same bits as
+// with fma, fma, v_max_f32 -- so a conv output is below 1 unless the true value exceeds 2^32, and
+// __builtin_amdgcn_fmed3f(fma(...), 0, 1) folds into `v_fma_f32 ... clamp` (hipcc folds it into the plain fma only: the
+// 10-filter net's packed path keeps its packed first fma and takes two clamped plain fmas per pair of positions).  One VALU
+// fewer per conv output: T1 -4.3 % (0.230 -> 0.220 ms per 2^20 frames), T2 the speed of round 2's re-associated "pivot" form
+// (fma + v_med3, sign and scale folded into the dense weights; 0.41 ms) in KERAS' operation order -- the pivot form, its
+// weight conditions and its option bit are gone (profiles/r03_dep_f32_clamp_ab.log).
 // RING > 0 (round 3; f32 frames, full blocks): the frames reach the lanes through a per-wave LDS ring of RING groups
 // (4 frames = 4 KiB each) filled by asm-issued LDS-DMA -- one global_load_lds_dwordx4 = one whole frame, 1 KiB contiguous,
 // landing lane-linear, read back by the same lane with one ds_read_b128: the registers hold exactly what the direct
@@ -191,7 +193,7 @@ __device__ __forceinline__ float rows_sum(float m) {       // sum over the four 
 // wave drains with vmcnt(0) before it ends (a copy must not land in LDS that already belongs to another work-group).
 // Round 2 tried this ring with the builtin and saw no gain: hipcc put a vmcnt(0) in front of every LDS read (DESIGN.md
 // 4.1b, "the LDS-DMA rings were not rings").
-template <int F, int TAP, int ABL = 0, bool TAIL = false, bool U8 = false, bool PIV = false, int RING = 0>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
+template <int F, int TAP, int ABL = 0, bool TAIL = false, bool U8 = false, int RING = 0>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
 __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restrict__ x, long n,
                                                            const float* __restrict__ wp,
                                                            float* __restrict__ probs, int* __restrict__ labels,
@@ -349,15 +351,10 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                     for (int ff = 0; ff < F; ++ff)
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) {
-                            f32x2 y;
-                            if constexpr (PIV) {      // head triple = (r, lo, hi)
-                                y = __builtin_elementwise_fma(f32x2{k0[ff], k0[ff]}, xm[pr], xc[pr]);
-                                y = f32x2{__builtin_amdgcn_fmed3f(y.x, k1[ff], cb[ff]), __builtin_amdgcn_fmed3f(y.y, k1[ff], cb[ff])};
-                            } else {
-                                y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff]}, xc[pr],
-                                                              __builtin_elementwise_fma(f32x2{k0[ff], k0[ff]}, xm[pr], f32x2{cb[ff], cb[ff]}));
-                                y = f32x2{fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
-                            }
+                            // one packed fma + two clamped fmas per pair of positions (ReLU in the clamp bit, see above)
+                            const f32x2 t = __builtin_elementwise_fma(f32x2{k0[ff], k0[ff]}, xm[pr], f32x2{cb[ff], cb[ff]});
+                            const f32x2 y = f32x2{__builtin_amdgcn_fmed3f(fmaf(k1[ff], xc[pr].x, t.x), 0.f, 1.f),
+                                                  __builtin_amdgcn_fmed3f(fmaf(k1[ff], xc[pr].y, t.y), 0.f, 1.f)};
                             a0 = __builtin_elementwise_fma(f32x2{wd[2 * pr][ff][0], wd[2 * pr + 1][ff][0]}, y, a0);
                             a1 = __builtin_elementwise_fma(f32x2{wd[2 * pr][ff][1], wd[2 * pr + 1][ff][1]}, y, a1);
                             a2 = __builtin_elementwise_fma(f32x2{wd[2 * pr][ff][2], wd[2 * pr + 1][ff][2]}, y, a2);
@@ -391,8 +388,7 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int ff = 0; ff < F; ++ff) {
-                        float y = fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff]));
-                        y = fmaxf(y, 0.f);
+                        const float y = __builtin_amdgcn_fmed3f(fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff])), 0.f, 1.f);      // -> v_fma_f32 ... clamp
                         s0 = fmaf(wd[s][ff][0], y, s0);
                         s1 = fmaf(wd[s][ff][1], y, s1);
                         s2 = fmaf(wd[s][ff][2], y, s2);
@@ -447,8 +443,8 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
         if (!(ABL & 1)) { eI = e_tab[myframe * 2 + 0]; eQ = e_tab[myframe * 2 + 1]; }
 #pragma unroll
         for (int ff = 0; ff < F; ++ff) {
-            const float yI = PIV ? __builtin_amdgcn_fmed3f(eI, k1[ff], cb[ff]) : fmaxf(fmaf(k1[ff], eI, cb[ff]), 0.f);      // x[h][-1] = 0: t = x[h][0]
-            const float yQ = PIV ? __builtin_amdgcn_fmed3f(eQ, k1[ff], cb[ff]) : fmaxf(fmaf(k1[ff], eQ, cb[ff]), 0.f);
+            const float yI = __builtin_amdgcn_fmed3f(fmaf(k1[ff], eI, cb[ff]), 0.f, 1.f);      // x[h][-1] = 0
+            const float yQ = __builtin_amdgcn_fmed3f(fmaf(k1[ff], eQ, cb[ff]), 0.f, 1.f);
 #pragma unroll
             for (int c = 0; c < kC; ++c) {
                 r[c] = fmaf(we0[(ff * kC + c) * 64 + 0], yI, r[c]);
@@ -482,11 +478,6 @@ __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restri
 }
 
 }  // namespace
-
-// F = 10 with a pivot table: the one-fma conv form.  Whether it runs is decided ONCE, in deployed_pack (mdc_finalize):
-// the table exists and the caller did not ask for Keras' operation order (MDC_OPT_KERAS_CONV_ORDER).  Nothing under
-// mdc_forward* reads the environment.
-static bool pivot_form(const mdc_model* m) { return m->dep_pivot; }
 
 static bool f32_mfma_variant(const mdc_model* m) {
 #ifdef MDC_ALTERNATES
@@ -524,53 +515,13 @@ int deployed_pack(mdc_model* m) {
     }
     int rc = upload(m, 0, pk.data(), pk.size() * sizeof(float));
     if (rc != MDC_OK) return rc;
-    // the pivot table (F = 10 only; see deployed_fwd_kernel): needs every K1[f] != 0 with a ratio K0/K1 that stays a normal
-    // float -- otherwise slot 6 stays empty and the plain form runs
-    m->dep_pivot = false;
-    if (F == 10 && !(m->topo.reserved[0] & MDC_OPT_KERAS_CONV_ORDER)) {
-        bool ok = true;
-        for (int f = 0; f < F; ++f) {
-            const double k0 = ck[0 * F + f], k1 = ck[1 * F + f];
-            if (k1 == 0.0 || !(std::fabs(k0 / k1) < 1e6) || !(std::fabs((double)m->hb[0][f] / k1) < 1e30)) ok = false;
-        }
-        // An inactive output contributes D' * (-beta) that the folded constant sum(D' * beta) = sum(D * b) must cancel: exact
-        // in exact arithmetic, 2^-24 * sum|D||b| at worst in f32.  Large conv biases therefore keep the plain form
-        // (bundled 10-filter net: sum|D||b| = 16, 7, 3 per class -> 1e-6 worst case, 1e-8 typical).
-        for (int c = 0; c < kC && ok; ++c) {
-            double absc = 0.0;
-            for (int h = 0; h < 2; ++h)
-                for (int w = 0; w < 129; ++w)
-                    for (int f = 0; f < F; ++f) absc += std::fabs((double)dk[((size_t)h * 129 * F + (size_t)w * F + f) * kC + c] * (double)m->hb[0][f]);
-            if (!(absc <= 32.0)) ok = false;
-        }
-        if (ok) {
-            std::vector<float> pv(pk);
-            std::vector<double> scale(F), beta(F);
-            const float inf = std::numeric_limits<float>::infinity();
-            for (int f = 0; f < F; ++f) {
-                const double k0 = ck[0 * F + f], k1 = ck[1 * F + f];
-                beta[f] = (double)m->hb[0][f] / k1;
-                scale[f] = k1;                                   // sign(p) * |p|
-                pv[3 * f + 0] = (float)(k0 / k1);                // r
-                pv[3 * f + 1] = k1 > 0 ? (float)-beta[f] : -inf; // lo
-                pv[3 * f + 2] = k1 > 0 ? inf : (float)-beta[f];  // hi
-            }
-            double cst[kC] = {0.0, 0.0, 0.0};
-            for (int h = 0; h < 2; ++h)
-                for (int w = 0; w < 129; ++w)
-                    for (int f = 0; f < F; ++f)
-                        for (int c = 0; c < kC; ++c) cst[c] += (double)dk[((size_t)h * 129 * F + (size_t)w * F + f) * kC + c] * scale[f] * beta[f];
-            for (int c = 0; c < kC; ++c) pv[3 * F + c] = (float)((double)m->hb[1][c] + cst[c]);
-            for (int lane = 0; lane < 64; ++lane)
-                for (int sl = 0; sl < kSlots; ++sl)
-                    for (int f = 0; f < F; ++f)
-                        for (int c = 0; c < kC; ++c) {
-                            const size_t i = kHeadFloats + ((size_t)(sl * F + f) * kC + c) * 64 + lane;
-                            pv[i] = (float)((double)pk[i] * scale[f]);
-                        }
-            if ((rc = upload(m, 6, pv.data(), pv.size() * sizeof(float))) != MDC_OK) return rc;
-            m->dep_pivot = true;
-        }
+    {   // the fast kernel's table (slot 5): taps and conv bias x 2^-32, dense weights x 2^+32 -- exact; the ReLU then rides in
+        // the fma's clamp bit (deployed_fwd_kernel).  Slot 0 stays unscaled: the tap kernel, the f16 mode's conversion
+        // of the taps and the alternates' f32-MFMA variant read it.
+        std::vector<float> ps(pk);
+        for (int f = 0; f < 3 * F; ++f) ps[f] = std::ldexp(pk[f], -32);
+        for (size_t i = kHeadFloats; i < ps.size(); ++i) ps[i] = std::ldexp(pk[i], 32);
+        if ((rc = upload(m, 5, ps.data(), ps.size() * sizeof(float))) != MDC_OK) return rc;
     }
 #ifdef MDC_ALTERNATES
     return deployed_f32m_pack(m);      // + the dense layer as f32 MFMA operands (deployed_f32m.hip)
@@ -586,9 +537,8 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
         if (tap_kind != MDC_TAP_NONE) { set_error("layer taps of the deployed nets are served by the f32 kernels (finalize with MDC_F32)"); return MDC_ENOTSUP; }
         return deployed_bf16_forward(m, x, n, probs, labels, s);
     }
-    const float* wp = static_cast<const float*>(m->d_pack[0]);
-    const float* wpv = static_cast<const float*>(m->d_pack[6]);      // pivot-form table (F = 10), if any
-    const bool piv = pivot_form(m);
+    const float* wp0 = static_cast<const float*>(m->d_pack[0]);      // unscaled table: the one-frame-at-a-time tap kernel
+    const float* wp = static_cast<const float*>(m->d_pack[5]);       // scaled table of the fast kernel (ReLU in the clamp bit)
     const int F = m->topo.filters;
     float* tap_conv = (tap_kind == MDC_TAP_CONV || tap_kind == MDC_TAP_FLAT) ? tap : nullptr;
     float* tap_dense = (tap_kind == MDC_TAP_DENSE) ? tap : nullptr;
@@ -634,8 +584,8 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
 #define MDC_LAUNCH_RING(R) do { \
             constexpr int lds = 4 * R * 4096, per_cu = (160 * 1024) / (lds + 2048); \
             long g = (nfull / 64 + 3) / 4; if (g > 256L * per_cu) g = 256L * per_cu; \
-            MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_fwd_kernel<3, 0, 0, false, false, false, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, false, false, false, R>), dim3((unsigned)g), dim3(256), lds, s, x, nfull, wp, probs, labels, tap_dense); } while (0)
+            MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deployed_fwd_kernel<3, 0, 0, false, false, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, false, false, R>), dim3((unsigned)g), dim3(256), lds, s, x, nfull, wp, probs, labels, tap_dense); } while (0)
             switch (ring) {
                 case 2: MDC_LAUNCH_RING(2); break;
                 case 3: MDC_LAUNCH_RING(3); break;
@@ -647,11 +597,9 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
 #endif
         } else if (tap_dense) {
             if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
-            else if (piv) hipLaunchKernelGGL((deployed_fwd_kernel<10, 2, 0, false, false, true>), dim3(grid), dim3(256), 0, s, x, nfull, wpv, probs, labels, tap_dense);
             else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 2>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
         } else {
             if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
-            else if (piv) hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, x, nfull, wpv, probs, labels, tap_dense);
             else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0>), dim3(grid), dim3(256), 0, s, x, nfull, wp, probs, labels, tap_dense);
         }
     }
@@ -664,15 +612,13 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
         float* td = tap_dense ? tap_dense + nfull * 3 : nullptr;
         if (tc) {       // conv/flat tap: the one-frame-at-a-time kernel over the whole batch
             const long g2 = ((nt + 63) / 64 + 3) / 4 > 2048 ? 2048 : ((nt + 63) / 64 + 3) / 4;
-            if (F == 3) hipLaunchKernelGGL((deployed_tap_kernel<3, 1>), dim3((unsigned)g2), dim3(256), 0, s, xt, nt, wp, pt, lt, tc, td);
-            else        hipLaunchKernelGGL((deployed_tap_kernel<10, 1>), dim3((unsigned)g2), dim3(256), 0, s, xt, nt, wp, pt, lt, tc, td);
+            if (F == 3) hipLaunchKernelGGL((deployed_tap_kernel<3, 1>), dim3((unsigned)g2), dim3(256), 0, s, xt, nt, wp0, pt, lt, tc, td);
+            else        hipLaunchKernelGGL((deployed_tap_kernel<10, 1>), dim3((unsigned)g2), dim3(256), 0, s, xt, nt, wp0, pt, lt, tc, td);
         } else if (td) {
             if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 2, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
-            else if (piv) hipLaunchKernelGGL((deployed_fwd_kernel<10, 2, 0, true, false, true>), dim3(1), dim3(64), 0, s, xt, nt, wpv, pt, lt, td);
             else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 2, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
         } else {
             if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
-            else if (piv) hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true, false, true>), dim3(1), dim3(64), 0, s, xt, nt, wpv, pt, lt, td);
             else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, td);
         }
     }
@@ -683,9 +629,7 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
 // Raw SDR bytes straight into the deployed nets: full 64-frame blocks by the fast kernel,
 // a ragged tail by its TAIL form; no frame buffer in between.
 int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int64_t hop, float scale, float* probs, int32_t* labels, hipStream_t s) {
-    const float* wp = static_cast<const float*>(m->d_pack[0]);
-    const float* wpv = static_cast<const float*>(m->d_pack[6]);
-    const bool piv = pivot_form(m);
+    const float* wp = static_cast<const float*>(m->d_pack[5]);       // scaled table of the fast kernel
     const int F = m->topo.filters;
     const long nfull = (n / 64) * 64;
     const long hop2 = 2 * (long)hop;
@@ -698,7 +642,6 @@ int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int
         long grid = (nfull / 64 + 3) / 4;
         if (grid > 2048) grid = 2048;
         if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale, hop2);
-        else if (piv) hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, false, true, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wpv, probs, labels, nullptr, scale, hop2);
         else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, false, true>), dim3(grid), dim3(256), 0, s, xb, nfull, wp, probs, labels, nullptr, scale, hop2);
     }
     if (nfull < n) {
@@ -707,7 +650,6 @@ int deployed_forward_iq_u8(const mdc_model* m, const uint8_t* iq, int64_t n, int
         float* pt = probs ? probs + nfull * 3 : nullptr;
         int* lt = labels ? labels + nfull : nullptr;
         if (F == 3) hipLaunchKernelGGL((deployed_fwd_kernel<3, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale, hop2);
-        else if (piv) hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wpv, pt, lt, nullptr, scale, hop2);
         else        hipLaunchKernelGGL((deployed_fwd_kernel<10, 0, 0, true, true>), dim3(1), dim3(64), 0, s, xt, nt, wp, pt, lt, nullptr, scale, hop2);
     }
     MDC_HIP(hipGetLastError());

@@ -85,7 +85,6 @@ struct mdc_model {
 
     // fp8 mode (vtcnn2): largest |sample| the caller expects (sets the activation scale); fp8_feat_scale_log2 holds the
     // E8M0 block-scale byte the fp8 conv kernel hands its MFMAs (vtcnn2_fp8_conv.hip)
-    bool dep_pivot = false;      // deployed F = 10: the pivot-form table (d_pack[6]) exists AND is the form that runs (deployed.hip)
     // Alternate kernels exist only in the -DMDC_ALTERNATES test build (libmdc_alt.so); there mdc_create reads the
     // selecting environment variables ONCE into this field (mdc::kAlt* bits).  Always 0 in the product library: no entry
     // point under mdc_forward* reads the environment.

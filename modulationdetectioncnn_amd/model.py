@@ -50,15 +50,13 @@ class VTCNN2:
     MAX_WORKSPACES = 4
 
     def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
-                 fp8_input_absmax: Optional[float] = None, keras_conv_order: bool = False, _lib_variant: str = "product"):
+                 fp8_input_absmax: Optional[float] = None, _lib_variant: str = "product"):
         """dtype "f32" | "bf16" (vtcnn2, deployed) | "f16" (deployed) | "fp8" (vtcnn2, deployed).  fp8_input_absmax: the largest
         |I/Q sample| the fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs saturate.
-        keras_conv_order (MDC_OPT_KERAS_CONV_ORDER): the 10-filter deployed net at f32 keeps Keras' two-fma conv instead of
-        the re-associated pivot form (same function within 2e-6; 7-9 % slower).  _lib_variant: tests only (the alternates build)."""
+        _lib_variant: tests only (the alternates build)."""
         self.topology = topology
         self.dtype = dtype
         self.fp8_input_absmax = fp8_input_absmax
-        self.keras_conv_order = bool(keras_conv_order)
         self._lib_variant = _lib_variant
         if dtype not in _DTYPE:
             raise ValueError(f"dtype must be one of {sorted(_DTYPE)}")
@@ -211,8 +209,7 @@ class VTCNN2:
             raise RuntimeError("no ROCm device visible: the MI355X path has no CPU fallback")
         L = self._lib()
         t = self.topology
-        opts = _cabi.OPT_KERAS_CONV_ORDER if self.keras_conv_order else 0
-        topo = _cabi.MdcTopology(_KIND[t.kind], t.filters, t.hidden, t.classes, (C.c_int32 * 4)(opts, 0, 0, 0))
+        topo = _cabi.MdcTopology(_KIND[t.kind], t.filters, t.hidden, t.classes, (C.c_int32 * 4)(0, 0, 0, 0))
         h = C.c_void_p()
         self._check(L.mdc_create(C.byref(topo), self.device_index, C.byref(h)))
         try:

@@ -93,7 +93,7 @@ def test_header_is_plain_c99(tmp_path):
     """include/mdc.h compiles as C99 with -Wall -Werror -pedantic and nothing but the standard headers."""
     import subprocess
     src = tmp_path / "hdr.c"
-    src.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 3 && MDC_HOP_FRAME == 128 && MDC_OPT_KERAS_CONV_ORDER == 1 ? 0 : 1; }\n')
+    src.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 3 && MDC_HOP_FRAME == 128 && MDC_OPT_ALL == 0 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "hdr")], check=True)
     assert subprocess.run([str(tmp_path / "hdr")]).returncode == 0
 

@@ -441,69 +441,63 @@ def test_fp8_mode_of_the_deployed_nets(name):
     assert np.abs(mbig.predict(xl) - refl["probs"]).max() < 8e-2
 
 
-# ---- F = 10, f32: the pivot form of the conv (one fma + one med3 per output; deployed.hip) and the plain form behind it
+# ---- f32: the ReLU rides in the clamp bit of the conv's second fma, on a table scaled by exact powers of two (deployed.hip)
+@pytest.mark.parametrize("name", ["3convmodrecnets_CNN2_0.5", "convmodrecnets_CNN2_0.5"])
 @pytest.mark.parametrize("n", [1, 63, 65, 70001])
-def test_pivot_and_plain_conv_forms_both_meet_the_oracle(monkeypatch, n):
-    """The bundled 10-filter net takes the pivot form (every K1 != 0); keras_conv_order=True (MDC_OPT_KERAS_CONV_ORDER, fixed
-    when the model is created) keeps the plain two-fma form.  Both are held to the f64 oracle at the f32 bar, and they
-    agree with each other."""
-    name = "convmodrecnets_CNN2_0.5"
+def test_clamp_relu_conv_meets_the_oracle_and_the_unscaled_tap_kernel(name, n):
+    """The fast kernel's table carries taps/bias x 2^-32 and dense weights x 2^+32; the one-frame-at-a-time tap kernel
+    reads the UNSCALED table and takes fmaxf.  Both are held to the f64 oracle at the f32 bar, and the conv activations the
+    tap kernel reports are the ones the fast kernel's probabilities are consistent with."""
     x = synthetic_frames(n, seed=77) * np.float32(2.5)
     w = [a for p in load_deployed_npz(name) for a in p]
     ref = O.forward_deployed(x, *w, dtype=np.float64)
     scale = max(1.0, float(np.abs(ref["dense"]).max()))
-    got = {}
-    for form in ("1", "0"):
-        m = _model(name, keras_conv_order=(form == "0"))
-        d, p, l = m.predict(x, tap="dense"), m.predict(x), m.predict_classes(x)
-        np.testing.assert_allclose(d, ref["dense"], rtol=0, atol=2e-6 * scale)
-        np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
-        _check_labels(l, ref)
-        got[form] = (d, p, l)
-    np.testing.assert_allclose(got["1"][1], got["0"][1], rtol=0, atol=1e-6)
-    assert not np.array_equal(got["1"][0], got["0"][0]) or n == 1      # they ARE different arithmetic (n = 1 may coincide)
+    m = _model(name)
+    d, p, l = m.predict(x, tap="dense"), m.predict(x), m.predict_classes(x)
+    np.testing.assert_allclose(d, ref["dense"], rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
+    _check_labels(l, ref)
+    conv = m.predict(x[:64], tap="conv")      # unscaled table, plain max
+    np.testing.assert_allclose(conv, ref["conv"][:64], rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref["conv"]).max())))
 
 
-def test_degenerate_conv_taps_fall_back_to_the_plain_form(monkeypatch):
-    """A filter whose second tap is zero (or whose tap ratio is huge) has no pivot: the library must run the plain form
-    -- the results are then bit-identical with and without keras_conv_order -- and still meet the oracle."""
+def test_clamp_relu_conv_with_zero_tiny_and_huge_taps():
+    """Zero and denormal-after-scaling taps and conv biases far above the activations: the scaled table must stay the same
+    function (documented range of exactness: |tap|, |bias| >= 2^-94 or 0, activations < 2^32)."""
     topo = Topology.deployed(10, 3)
     (ck, cb), (dk, db) = synthetic_weights(topo, seed=5, bias_scale=0.05)
     ck = np.array(ck, np.float32)
-    ck.reshape(2, 10)[1, 3] = 0.0            # K1[3] = 0
-    ck.reshape(2, 10)[1, 7] = 1e-30          # |K0/K1| ~ 1e29
+    ck.reshape(2, 10)[1, 3] = 0.0
+    ck.reshape(2, 10)[1, 7] = 1e-30          # x 2^-32 is an f32 denormal: its contribution (~1e-30) is below every bar
     x = synthetic_frames(5000, seed=8) * np.float32(3.0)
     ref = O.forward_deployed(x, ck, cb, dk, db, dtype=np.float64)
-    outs = []
-    for form in ("1", "0"):
-        m = VTCNN2(topo, keras_conv_order=(form == "0"))
-        m.set_weights([(ck, cb), (dk, db)])
-        p = m.predict(x)
-        np.testing.assert_allclose(p, ref["probs"], rtol=0, atol=2e-6)
-        outs.append(p)
-    np.testing.assert_array_equal(outs[0], outs[1])
-    # large conv biases: the folded constant sum(D*b) would have to cancel large inactive terms -> plain form as well
+    m = VTCNN2(topo)
+    m.set_weights([(ck, cb), (dk, db)])
+    np.testing.assert_allclose(m.predict(x), ref["probs"], rtol=0, atol=2e-6)
     (ck2, cb2), (dk2, db2) = synthetic_weights(topo, seed=6, bias_scale=0.05)
     cb2 = np.full(10, 5.0, np.float32)
     ref2 = O.forward_deployed(x, ck2, cb2, dk2, db2, dtype=np.float64)
-    outs = []
-    for form in ("1", "0"):
-        m = VTCNN2(topo, keras_conv_order=(form == "0"))
-        m.set_weights([(ck2, cb2), (dk2, db2)])
-        d = m.predict(x, tap="dense")
-        np.testing.assert_allclose(d, ref2["dense"], rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref2["dense"]).max())))
-        outs.append(d)
-    np.testing.assert_array_equal(outs[0], outs[1])
+    m = VTCNN2(topo)
+    m.set_weights([(ck2, cb2), (dk2, db2)])
+    d = m.predict(x, tap="dense")
+    np.testing.assert_allclose(d, ref2["dense"], rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref2["dense"]).max())))
+    # activations of 1e6 (inputs x 1e6): far inside the clamp's 2^32 ceiling
+    xb = x[:512] * np.float32(1e5)
+    refb = O.forward_deployed(xb, ck, cb, dk, db, dtype=np.float64)
+    m2 = VTCNN2(topo)
+    m2.set_weights([(ck, cb), (dk, db)])
+    got = m2.predict(xb, tap="dense")
+    np.testing.assert_allclose(got, refb["dense"], rtol=0, atol=4e-6 * max(1.0, float(np.abs(refb["dense"]).max())))
 
 
-def test_pivot_form_negative_and_positive_pivots_with_biases():
-    """both signs of K1, biases of both signs and a saturating input scale: the (lo, hi) clamp and the folded constants"""
+def test_conv_taps_of_both_signs_with_biases_and_saturating_inputs():
+    """both signs of the second tap, biases of both signs and a saturating input scale"""
     topo = Topology.deployed(10, 3)
     rng = np.random.default_rng(11)
     ck = rng.normal(0, 1, (1, 2, 1, 10)).astype(np.float32)
     ck.reshape(2, 10)[1] = np.array([-2, -1, -0.5, -0.25, -3, 2, 1, 0.5, 0.25, 3], np.float32)
     cb = rng.normal(0, 0.05, 10).astype(np.float32)
-    dk = rng.normal(0, 0.05, (2580, 3)).astype(np.float32)      # sum|D||b| ~ 5: pivot form
+    dk = rng.normal(0, 0.05, (2580, 3)).astype(np.float32)
     db = np.array([0.3, -0.2, 0.1], np.float32)
     m = VTCNN2(topo)
     m.set_weights([(ck, cb), (dk, db)])

@@ -49,8 +49,8 @@ spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in th
     ("mdc_vt_dense1/fp8", "vtfp8", "vt_dense1_bf16", 1 << 20),
     ("mdc_vt_conv/f32", "vtf32", "vt_conv_f32_kernel", 1 << 16),
     ("mdc_vt_dense1/f32", "vtf32", "vt_dense1_f32_kernel", 1 << 16),
-    ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3, 0, 0, false, false, false, 0>", 1 << 20),      # <F, TAP, ABL, TAIL, U8, PIV, RING>
-    ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10, 0, 0, false, false, true, 0>", 1 << 20),      # the pivot form (bundled net)
+    ("mdc_deployed_fwd/F3", "dep", "deployed_fwd_kernel<3, 0, 0, false, false, 0>", 1 << 20),      # <F, TAP, ABL, TAIL, U8, RING>
+    ("mdc_deployed_fwd/F10", "dep", "deployed_fwd_kernel<10, 0, 0, false, false, 0>", 1 << 20),
     # deployed_bf16_kernel<F, MODE, U8>: MODE 0 bf16, 1 f16, 2 fp8
     ("mdc_deployed_fwd/F3/bf16", "dep", "deployed_bf16_kernel<3, 0, false>", 1 << 20),
     ("mdc_deployed_fwd/F10/bf16", "dep", "deployed_bf16_kernel<10, 0, false>", 1 << 20),
@@ -61,8 +61,8 @@ spec = [  # (json key, pmc dir suffix, kernel substring, frames per launch in th
     ("mdc_deployed_q612/F3", "dep", "deployed_q612_kernel<3>", 1 << 20),
     ("mdc_deployed_q612/F10", "dep", "deployed_q612_kernel<10>", 1 << 20),
     # raw uint8 I/Q input (256 B/frame): the U8 = true forms of the same kernels
-    ("mdc_deployed_fwd/F3/u8", "dep", "deployed_fwd_kernel<3, 0, 0, false, true, false, 0>", 1 << 20),
-    ("mdc_deployed_fwd/F10/u8", "dep", "deployed_fwd_kernel<10, 0, 0, false, true, true, 0>", 1 << 20),
+    ("mdc_deployed_fwd/F3/u8", "dep", "deployed_fwd_kernel<3, 0, 0, false, true, 0>", 1 << 20),
+    ("mdc_deployed_fwd/F10/u8", "dep", "deployed_fwd_kernel<10, 0, 0, false, true, 0>", 1 << 20),
     ("mdc_deployed_fwd/F3/bf16/u8", "dep", "deployed_bf16_kernel<3, 0, true>", 1 << 20),
     ("mdc_deployed_fwd/F10/bf16/u8", "dep", "deployed_bf16_kernel<10, 0, true>", 1 << 20),
     ("mdc_deployed_fwd/F3/f16/u8", "dep", "deployed_bf16_kernel<3, 1, true>", 1 << 20),
