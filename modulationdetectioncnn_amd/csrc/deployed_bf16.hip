@@ -87,12 +87,21 @@ __device__ __forceinline__ unsigned pack2clamp(float a, float b) {
     return r;
 }
 
-// four f32 -> four e4m3 in one dword (byte i = value i), ReLU and saturation at the e4m3 maximum by one v_med3_f32 each
-__device__ __forceinline__ unsigned pack4relu_fp8(float a, float b, float c, float d) {
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, 0.f, 448.f), __builtin_amdgcn_fmed3f(b, 0.f, 448.f), 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, 0.f, 448.f), __builtin_amdgcn_fmed3f(d, 0.f, 448.f), w, true);
-    return (unsigned)w;
+// fp8 mode (round 3): four conv outputs -> four e4m3 in one dword (byte i = value i) by two v_cvt_scalef32_pk_fp8_f32.  The
+// values arrive already rectified -- the conv's second fma carries the clamp bit: taps and bias are scaled by 2^(sa-9), so
+// [0, 1] is [0, 512) in e4m3 units -- and the conversion divides by its scale operand 2^-9; (448, 512) saturates to 448
+// because the kernel sets MODE.FP16_OVFL (without it the OCP conversion returns NaN there;
+// tools/microbench/cvt_fp8_bf16_probe.hip).  Round 2 spent a v_med3_f32(x, 0, 448) per value on the same thing.
+constexpr int kFp8ClampShift = 9;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    const float sc = 0x1p-9f;
+    s16x2 w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, a, b, sc, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c, d, sc, true);
+    return __builtin_bit_cast(unsigned, w);
 }
+__device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 1.f); }      // after an fma: folds into its clamp bit
 
 // U8 = true (mdc_forward_iq_u8): x points at raw interleaved unsigned 8-bit (I,Q) samples, 256 B per frame.  A whole
 // group is then 4 KiB (one DMA instruction = four frames), the wave's staging area holds a ring of FOUR groups
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
     constexpr int kPhaseUnits = G::kUnits / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* a_lds = reinterpret_cast<uint4*>(smem);
+    if constexpr (FP8) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");      // FP16_OVFL: the e4m3 conversions saturate (pack4_fp8)
     for (int i = threadIdx.x; i < G::kATabBytes / 16; i += blockDim.x) a_lds[i] = atab[i];
     __syncthreads();
 
@@ -248,7 +258,19 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                         const float xs[5] = {c4[q].x, c4[q].y, c4[q].z, c4[q].w, nbv[q]};
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            if constexpr (F % 2 == 0) {
+                            if constexpr (FP8) {      // ReLU in the second fma's clamp bit (pack4_fp8)
+                                if constexpr (F % 2 == 0) {
+#pragma unroll
+                                    for (int ff = 0; ff < F; ff += 2) {
+                                        const f32x2 t = __builtin_elementwise_fma(f32x2{k0[ff], k0[ff + 1]}, f32x2{xs[s], xs[s]}, f32x2{cb[ff], cb[ff + 1]});
+                                        vals[(q * 4 + s) * F + ff] = clamp01(fmaf(k1[ff], xs[s + 1], t.x));
+                                        vals[(q * 4 + s) * F + ff + 1] = clamp01(fmaf(k1[ff + 1], xs[s + 1], t.y));
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int ff = 0; ff < F; ++ff) vals[(q * 4 + s) * F + ff] = clamp01(fmaf(k1[ff], xs[s + 1], fmaf(k0[ff], xs[s], cb[ff])));
+                                }
+                            } else if constexpr (F % 2 == 0) {
 #pragma unroll
                                 for (int ff = 0; ff < F; ff += 2) {
                                     const f32x2 y = __builtin_elementwise_fma(f32x2{k1[ff], k1[ff + 1]}, f32x2{xs[s + 1], xs[s + 1]},
@@ -265,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                     }
                     if constexpr (FP8) {
 #pragma unroll
-                        for (int i = 0; i < G::kUnitVals / 4; ++i) pk[i] = pack4relu_fp8(vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]);
+                        for (int i = 0; i < G::kUnitVals / 4; ++i) pk[i] = pack4_fp8(vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < G::kUnitVals / 2; ++i) pk[i] = pack2clamp(vals[2 * i], vals[2 * i + 1]);
@@ -316,8 +338,8 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
             for (int i = 0; i < 8 * G::kExtraMfma; ++i) ev[i] = 0.f;
 #pragma unroll
             for (int ff = 0; ff < F; ++ff) {
-                ev[ff] = fmaf(k1[ff], x0[0], cb[ff]);
-                ev[F + ff] = fmaf(k1[ff], x0[1], cb[ff]);
+                ev[ff] = FP8 ? clamp01(fmaf(k1[ff], x0[0], cb[ff])) : fmaf(k1[ff], x0[0], cb[ff]);
+                ev[F + ff] = FP8 ? clamp01(fmaf(k1[ff], x0[1], cb[ff])) : fmaf(k1[ff], x0[1], cb[ff]);
             }
 #pragma unroll
             for (int mm = 0; mm < G::kExtraMfma; ++mm) {
@@ -345,8 +367,8 @@ __global__ __launch_bounds__(512, 1) void deployed_bf16_kernel(const float* __re
                     }
                     acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, u32x4{w[0], w[1], w[2], w[3]}), acc[m & 1], 0, 0, 0);
                 } else if constexpr (FP8) {
-                    const unsigned lo = pack4relu_fp8(ev[8 * mm + 0], ev[8 * mm + 1], ev[8 * mm + 2], ev[8 * mm + 3]);
-                    const unsigned hi = pack4relu_fp8(ev[8 * mm + 4], ev[8 * mm + 5], ev[8 * mm + 6], ev[8 * mm + 7]);
+                    const unsigned lo = pack4_fp8(ev[8 * mm + 0], ev[8 * mm + 1], ev[8 * mm + 2], ev[8 * mm + 3]);
+                    const unsigned hi = pack4_fp8(ev[8 * mm + 4], ev[8 * mm + 5], ev[8 * mm + 6], ev[8 * mm + 7]);
                     acc[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(((unsigned long)a.y << 32) | a.x), (long)(((unsigned long)hi << 32) | lo), acc[m & 1], 0, 0, 0);
                 } else {
                     const u32x4 b = u32x4{pack2clamp(ev[8 * mm + 0], ev[8 * mm + 1]), pack2clamp(ev[8 * mm + 2], ev[8 * mm + 3]),
@@ -451,7 +473,7 @@ void pack_atab(const mdc_model* m, std::vector<unsigned short>& tab, float wscal
 }  // namespace
 
 // d_pack slot 2: the dense layer as MFMA A operands (bf16 / f16 / e4m3).  fp8 mode also builds its own head (slot 4):
-// conv taps and bias x 2^sa, dense bias, 2^-(sa+sw) -- the f32 head of slot 0 stays as it is for the Q6.12 tables' sake.
+// conv taps and bias x 2^(sa-9) (the e4m3 values carry 2^sa), dense bias, 2^-(sa+sw) -- the f32 head of slot 0 stays as it is for the Q6.12 tables' sake.
 int deployed_bf16_pack(mdc_model* m) {
     const int F = m->topo.filters;
     float wscale = 1.f;
@@ -462,7 +484,7 @@ int deployed_bf16_pack(mdc_model* m) {
         for (float w : m->hk[1]) wmax = std::fmax(wmax, std::fabs(w));
         if (!(cbound > 0.f) || !(wmax > 0.f)) { set_error("fp8: degenerate weights (all zero)"); return MDC_EINVAL; }
         const int sa = (int)std::floor(std::log2(224.f / cbound)), sw = (int)std::floor(std::log2(224.f / wmax));      // a factor 2 of head-room
-        const float fsa = std::ldexp(1.f, sa);
+        const float fsa = std::ldexp(1.f, sa - kFp8ClampShift);      // the kernel's conversion multiplies by 2^9 again (pack4_fp8)
         wscale = std::ldexp(1.f, sw);
         std::vector<float> head(64, 0.f);
         for (int f = 0; f < F; ++f) {
