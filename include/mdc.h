@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define MDC_ABI_VERSION 3   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows
-                               3: mdc_topology.reserved[0] carries MDC_OPT_* bits (additive: 0 = the behaviour of 2) */
+                               3: mdc_topology.reserved[0] is a validated option word (no bit defined: must be 0);
+                                  mdc_iq_u8_windows wants 2-byte aligned input; the library reads no environment */
 
 /* error codes (negative errno values) */
 #define MDC_OK        0
