@@ -63,6 +63,9 @@ enum {
  * MDC_KIND_VTCNN2 in the 16-bit modes keeps its activations and features multiplied by 2^-32 internally (an exact
  * power of two; the ReLU then rides in the bf16 conversion's clamp bit): conv1 / conv2 activations of 2^32 (4.3e9)
  * and beyond saturate, those below 2^-94 flush to zero -- I/Q samples of order 1e-2 sit in the middle of that range.
+ * MDC_KIND_DEPLOYED does the same with its conv taps and bias at MDC_F32 and MDC_BF16 (the ReLU rides in the second
+ * fma's / the conversion's clamp bit; dense weights carry the 2^+32): identical bits inside that range, conv
+ * activations of 2^32 and beyond saturate there instead of growing on (tests/test_deployed_gpu.py pins it).
  * MDC_F16: MDC_KIND_DEPLOYED only -- as MDC_BF16 there, with IEEE f16 operands and the conv itself in packed f16
  * (11 significant bits instead of 8, but conv outputs must stay below 65,504).
  * MDC_FP8: MDC_KIND_VTCNN2 -- conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16) -- and

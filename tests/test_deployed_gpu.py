@@ -492,6 +492,30 @@ def test_clamp_relu_conv_with_zero_tiny_and_huge_taps():
     np.testing.assert_allclose(got, refb["dense"], rtol=0, atol=4e-6 * max(1.0, float(np.abs(refb["dense"]).max())))
 
 
+def test_activations_beyond_the_documented_range_saturate_at_2_pow_32():
+    """include/mdc.h: conv activations of 2^32 and beyond saturate (the clamp bit's [0, 1] on the 2^-32-scaled table).  Pinned
+    here so the behaviour cannot drift: frames 1e12 times the bundled level give the f64 oracle's result with its conv
+    output clipped at 2^32, finite probabilities, and leave the other frames of the batch untouched."""
+    name = "3convmodrecnets_CNN2_0.5"
+    w = [a for p in load_deployed_npz(name) for a in p]
+    x = synthetic_frames(256, seed=21)
+    big = x.copy()
+    big[100:104] *= np.float32(1e12)
+    ref = O.forward_deployed(big.astype(np.float64), *w, dtype=np.float64)
+    flat = np.minimum(ref["conv"], 2.0 ** 32).reshape(256, -1)
+    dense = np.maximum(flat @ np.asarray(w[2], np.float64) + np.asarray(w[3], np.float64), 0.0)
+    m = _model(name)
+    got = m.predict(big, tap="dense")
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[100:104], dense[100:104], rtol=2e-6)
+    clean = m.predict(x, tap="dense")
+    keep = np.ones(256, bool)
+    keep[100:104] = False
+    np.testing.assert_array_equal(got[keep], clean[keep])
+    p = m.predict(big)
+    assert np.isfinite(p).all() and np.abs(p.sum(axis=1) - 1).max() < 1e-5
+
+
 def test_conv_taps_of_both_signs_with_biases_and_saturating_inputs():
     """both signs of the second tap, biases of both signs and a saturating input scale"""
     topo = Topology.deployed(10, 3)
