@@ -17,8 +17,9 @@
 // those slots are zero).  The dense part is 8F + 1..3 MFMAs per 16 frames.
 //
 // HALF = false (MDC_BF16): conv in f32 with the f32 kernel's fma chain (fma(K1, x[w], fma(K0, x[w-1], b)), two
-// filters per v_pk_fma_f32), outputs rounded to bf16 (v_cvt_pk_bf16_f32 + v_pk_max_i16); dense weights bf16.
-// 2 + 2 VALU per two outputs = 81 per frame for F = 10 instead of ~180 -- but v_pk_fma_f32 is a slow instruction here.
+// filters per v_pk_fma_f32), outputs rounded to bf16 AND rectified by one v_cvt_pk_bf16_f32 with the clamp bit (round 3,
+// pack2clamp below; round 2: v_cvt_pk_bf16_f32 + v_pk_max_i16); dense weights bf16.
+// 2 + 1 VALU per two outputs for F = 10 -- but v_pk_fma_f32 is a slow instruction here.
 // HALF = true (MDC_F16): IEEE f16 operands, and then the conv itself runs in packed f16 (v_pk_fma_f16 on 32-bit
 // registers: two filters per instruction at the plain VALU rate, ReLU = one v_pk_max_f16, no conversion before the
 // MFMA), which is what lifts the F = 10 net off the v_pk_fma_f32 bound.  f16 keeps 11 significant bits (bf16: 8) but
@@ -27,8 +28,9 @@
 // bf16 mode's f32 conv, its outputs and the dense weights as OCP e4m3 on v_mfma_f32_16x16x32_fp8_fp8 (8 one-byte k values
 // per lane).  e4m3 spans 2^-9 .. 448, so the conv's taps and bias are multiplied by 2^sa (sa from the largest |sample| the
 // caller states, mdc_set_fp8_input_absmax, default 0.02) and the dense weights by 2^sw on the host -- powers of two,
-// exact -- and the class sums are multiplied by 2^-(sa+sw) before the dense bias; ReLU is v_med3_f32(y, 0, 448), which also
-// saturates an input beyond the stated range instead of letting it become NaN.
+// exact -- and the class sums are multiplied by 2^-(sa+sw) before the dense bias; the ReLU rides in the conv's second fma
+// (clamp bit) and the scaled e4m3 conversion saturates under MODE.FP16_OVFL (round 3, pack4_fp8 below; round 2: a
+// v_med3_f32(y, 0, 448) per value), so an input beyond the stated range saturates instead of becoming NaN.
 // All: products accumulated in f32 by the MFMA; bias, ReLU, softmax, first-max argmax in f32 as in deployed.hip.
 #include "vtcnn2_bf16_common.h"
 
