@@ -4,7 +4,7 @@
 //   caller's pageable memory --(copy threads)--> pinned ring --(DMA, copy stream)--> HBM slot
 //        --(mdc_forward / mdc_forward_iq_u8, compute stream)--> results slot --(DMA, results stream)--> pinned --> caller
 //
-// Three slots of `chunk` frames: while chunk i is computed, chunk i+1 crosses PCIe and chunk i+2 is being copied into
+// Three slots of `chunk` frames (the first two chunks of a large batch are shorter: the fill ramp in run_pipeline): while chunk i is computed, chunk i+1 crosses PCIe and chunk i+2 is being copied into
 // pinned memory by the host threads, so the call runs at max(PCIe, kernel) instead of their sum (1 GiB of frames:
 // 18.9 ms of DMA at 57 GB/s; a plain hipMemcpy from pageable memory takes 63 ms the first time it sees the buffer;
 // tools/microbench/host_path.hip).  Memory that is already pinned (hipHostMalloc / hipHostRegister, e.g. a pinned
@@ -223,7 +223,7 @@ bool is_pinned(const void* p) { return host_kind(p) == 1; }
 
 // in_range(start, count) -> (byte offset, byte count) of the input those windows read; launch(d_in, count, slot, ctx)
 template <class InRange, class Launch>
-int run_pipeline(mdc_model* m, const char* src, int64_t n, int64_t chunk, float* probs_host, int32_t* labels_host,
+int run_pipeline(mdc_model* m, const char* src, int64_t n, int64_t chunk, bool ramp, float* probs_host, int32_t* labels_host,
                  InRange in_range, Launch launch) {
     HostCtx* c = static_cast<HostCtx*>(m->host_ctx);
     const int C = m->topo.classes;
@@ -243,10 +243,15 @@ int run_pipeline(mdc_model* m, const char* src, int64_t n, int64_t chunk, float*
     };
     int rc = MDC_OK;
     int64_t i = 0;
-    for (int64_t start = 0; start < n && rc == MDC_OK; start += chunk, ++i) {
+    // ramp (the library's own chunking of a large batch only): the first two chunks are a quarter and a half slot long, so
+    // the first kernel starts after 16 MiB have been staged and copied instead of 64 (the pipeline's fill time is paid
+    // once per call: 2 of 33.5 ms for 2^20 frames of VT-CNN2 bf16); results do not depend on chunking
+    int64_t count = 0;
+    for (int64_t start = 0; start < n && rc == MDC_OK; start += count, ++i) {
         Slot& s = c->slot[i % kSlots];
         if ((rc = retire(s)) != MDC_OK) break;      // chunk i - 3 is done with the slot's buffers
-        const int64_t count = std::min(chunk, n - start);
+        const int64_t len = ramp && i < 2 ? std::max<int64_t>(256, (chunk >> (2 - i)) & ~(int64_t)255) : chunk;
+        count = std::min(len, n - start);
         size_t off = 0, bytes = 0;
         in_range(start, count, &off, &bytes);
         hipError_t e;
@@ -315,7 +320,7 @@ int predict_host(mdc_model* m, const float* x_host, int64_t n, float* probs_host
     const int64_t chunk = std::min<int64_t>(chunk_frames > 0 ? chunk_frames : default_chunk(n), n);
     if ((rc = ctx_prepare(m, (size_t)chunk * kFrameFloats * 4, chunk)) != MDC_OK) return rc;
     return run_pipeline(
-        m, reinterpret_cast<const char*>(x_host), n, chunk, probs_host, labels_host,
+        m, reinterpret_cast<const char*>(x_host), n, chunk, chunk_frames <= 0 && n >= 4 * chunk, probs_host, labels_host,
         [](int64_t start, int64_t count, size_t* off, size_t* bytes) {
             *off = (size_t)start * kFrameFloats * 4;
             *bytes = (size_t)count * kFrameFloats * 4;
@@ -343,7 +348,7 @@ int predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int64_t 
     const size_t in_bytes = (size_t)(2 * hop) * (size_t)(chunk - 1) + 256;
     if ((rc = ctx_prepare(m, in_bytes, chunk)) != MDC_OK) return rc;
     return run_pipeline(
-        m, reinterpret_cast<const char*>(iq_host), n, chunk, probs_host, labels_host,
+        m, reinterpret_cast<const char*>(iq_host), n, chunk, chunk_frames <= 0 && n >= 4 * chunk, probs_host, labels_host,
         [hop](int64_t start, int64_t count, size_t* off, size_t* bytes) {
             *off = (size_t)(2 * hop) * (size_t)start;
             *bytes = (size_t)(2 * hop) * (size_t)(count - 1) + 256;
