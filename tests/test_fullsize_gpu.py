@@ -137,3 +137,30 @@ def test_dense1_kernels_agree_bit_for_bit():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dense1.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
     assert "bit-identical across kernels and repeats: True" in r.stdout
+
+
+@pytest.mark.parametrize("kind,dtype", [("deployed3", "f32"), ("deployed3", "bf16"), ("deployed10", "f32"), ("vtcnn2", "bf16")])
+def test_configs3_global_batch_in_one_call(kind, dtype):
+    """BASELINE configs[3]'s GLOBAL batch, 2^24 frames (+ a ragged 5), through ONE predict call on one GPU: 2^32 input floats,
+    so every frame offset past 2^23 frames needs 64-bit arithmetic in the kernels and in the host-side chunk loop (the
+    deployed nets take the batch in one launch, VT-CNN2 in 65,536-frame launches).  Slices at the start, across the
+    2^23-frame (2^31-float, 2^33-byte) boundary and at the ragged end must equal separate forwards of those slices, bit for bit."""
+    n = (1 << 24) + 5
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs 40 GB of free HBM")
+    m, topo, _ = _model(kind, dtype, 11 if kind == "vtcnn2" else 3)
+    x = torch.empty((n, 2, 128), dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(24)
+    for s in range(0, n, 1 << 22):      # filled in 4 GiB pieces (no second 16 GiB temporary)
+        e = min(n, s + (1 << 22))
+        x[s:e] = torch.randn((e - s, 2, 128), generator=g, device="cuda", dtype=torch.float32) * 5e-3
+    p, lab, _ = m.forward_device(x)
+    torch.cuda.synchronize()
+    assert p.shape == (n, topo.classes) and bool(torch.isfinite(p[:: 4099]).all())
+    for lo, hi in ((0, 300), ((1 << 23) - 150, (1 << 23) + 150), ((1 << 24) - 200, n)):
+        ps, ls, _ = m.forward_device(x[lo:hi].clone())
+        assert torch.equal(p[lo:hi], ps) and torch.equal(lab[lo:hi], ls), (kind, dtype, lo)
+    del x, p, lab
+    torch.cuda.empty_cache()
