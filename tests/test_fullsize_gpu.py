@@ -164,3 +164,34 @@ def test_configs3_global_batch_in_one_call(kind, dtype):
         assert torch.equal(p[lo:hi], ps) and torch.equal(lab[lo:hi], ls), (kind, dtype, lo)
     del x, p, lab
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind,dtype,hop", [("deployed3", "f32", 128), ("deployed3", "bf16", 128), ("deployed10", "f16", 128), ("deployed3", "f32", 200),
+                                            ("vtcnn2", "bf16", 128), ("vtcnn2", "f32", 1000)])
+def test_raw_iq_capture_beyond_4_gib(kind, dtype, hop):
+    """A raw uint8 I/Q capture longer than 2^32 bytes through one predict_iq_u8 call (window byte offsets 2 * hop * i need
+    64-bit arithmetic in the fused kernels): windows at the start, across the 2^32-byte boundary and at the end must equal
+    the forward of the same windows cut out of the capture."""
+    nwin = (1 << 24) + 37 if hop == 128 else ((1 << 32) // (2 * hop) + 4099)      # just past 2^32 bytes for the larger hops
+    nbytes = 2 * hop * (nwin - 1) + 256
+    assert nbytes > (1 << 32)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 * (1 << 30):
+        pytest.skip("needs 12 GB of free HBM")
+    m, topo, _ = _model(kind, dtype, 3)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    iq = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    for s in range(0, nbytes, 1 << 30):
+        e = min(nbytes, s + (1 << 30))
+        iq[s:e] = torch.randint(0, 256, (e - s,), generator=g, device="cuda", dtype=torch.uint8)
+    p, lab = m.predict_iq_u8(iq, 0.02 / 127.5, hop=hop)
+    torch.cuda.synchronize()
+    assert p.shape == (nwin, 3)
+    cross = (1 << 32) // (2 * hop)      # the window that straddles byte 2^32
+    for lo, hi in ((0, 100), (cross - 70, cross + 70), (nwin - 90, nwin)):
+        piece = iq[2 * hop * lo: 2 * hop * (hi - 1) + 256].clone()
+        ps, ls = m.predict_iq_u8(piece, 0.02 / 127.5, hop=hop)
+        assert torch.equal(p[lo:hi], ps) and torch.equal(lab[lo:hi], ls), (kind, dtype, hop, lo)
+    del iq, p, lab
+    torch.cuda.empty_cache()
