@@ -146,3 +146,23 @@ def test_out_arrays_and_the_multi_gpu_host_driver_on_one_gpu():
     p, l = msp.predict_host(x)
     np.testing.assert_array_equal(p, want_p)
     np.testing.assert_array_equal(l, want_l)
+
+
+def test_host_batch_beyond_4_gib_with_the_fill_ramp():
+    """A host array of more than 2^32 bytes (2^22 + 3 frames) through the streaming driver with the library's own chunking:
+    the fill ramp (first chunks a quarter and a half slot long), 65 full slots and a ragged tail; byte offsets into the
+    caller's array need 64 bits.  Slices at the start, around the ramp's chunk edges, across the 4 GiB boundary and at the
+    end must equal the device path's results for those frames."""
+    n = (1 << 22) + 3
+    block = synthetic_frames(1 << 16, seed=11)                       # 64 MiB, repeated with a per-repeat scale: no 4 GiB of RNG on the host
+    x = np.empty((n, 2, 128), np.float32)
+    for i, s in enumerate(range(0, n, 1 << 16)):
+        e = min(n, s + (1 << 16))
+        np.multiply(block[: e - s], np.float32(1.0 + 0.03125 * (i % 7)), out=x[s:e])
+    m = _t1()
+    p, l = m.predict_host(x)
+    assert p.shape == (n, 3) and l.shape == (n,)
+    for lo, hi in ((0, 500), (16384 - 100, 16384 + 100), (49152 - 100, 49152 + 100), ((1 << 22) - 200, n), (2097152 - 50, 2097152 + 50)):
+        want_p, want_l = _device_result(m, x[lo:hi])
+        np.testing.assert_array_equal(p[lo:hi], want_p)
+        np.testing.assert_array_equal(l[lo:hi], want_l)
