@@ -2,7 +2,10 @@
 """Headline benchmark: I/Q frames/s of the batched VT-CNN2 forward on MI355X.
 
 Contract (one JSON line on rank 0):  python bench.py --gpus N --steps K --warmup W
-For N>1 the driver launches one process per GPU with torch.distributed.run; frames are
+For N>1 the driver launches one process per GPU with torch.distributed.run (and when nobody
+does -- `python bench.py --gpus N` typed at a shell -- this file starts that launcher itself as a
+child process and relays rank 0's line; a launcher whose WORLD_SIZE disagrees with --gpus is
+refused with exit code 2, never silently measured as something else); frames are
 independent, so each rank runs the same per-GPU batch on its own shard with NO data-path
 collective ("scaling": "weak"); the only torch.distributed calls are the barriers around
 the timed region and the MAX of the elapsed time.
@@ -231,20 +234,54 @@ def launch_chunk(kind, dtype, n):
     return None
 
 
+class LegSkipped(RuntimeError):
+    """Raised on EVERY rank when any rank could not set a leg up (so no rank enters that leg's collectives alone)."""
+
+
+def agree_ok(dist, ok, what):
+    """All ranks learn whether every rank's setup succeeded: one tiny MAX-reduce of a failure flag, OUTSIDE the timed
+    region.  A rank that failed alone (e.g. out of HBM on a GPU it shares) must not leave its peers waiting in the
+    leg's barrier while it moves on to the next leg's."""
+    if not dist:
+        return bool(ok)
+    from modulationdetectioncnn_amd.sharding import all_reduce_array
+    failed = float(all_reduce_array(np.array([0.0 if ok else 1.0], np.float64), "max")[0])
+    if failed:
+        raise LegSkipped(f"{what}: set-up failed on at least one rank" + ("" if ok else " (this one)"))
+    return True
+
+
 def run_workload(name, device, steps, warmup, dist=None, frames=None):
     """frames: per-GPU batch of THIS rank when it differs from the workload's own (the strong-scaling leg)."""
     import torch
     from modulationdetectioncnn_amd import synthetic_frames
-    m, n, dtype = make_model(name, device)
-    if frames is not None:
-        n = int(frames)
-    rank = dist.get_rank() if dist else 0
-    x = synthetic_frames(n, seed=2016 + rank, device=f"cuda:{device}")
-    probs = torch.empty((n, m.topology.classes), dtype=torch.float32, device=x.device)
-    labels = torch.empty((n,), dtype=torch.int32, device=x.device)
+    err = None
+    try:
+        m, n, dtype = make_model(name, device)
+        if frames is not None:
+            n = int(frames)
+        rank = dist.get_rank() if dist else 0
+        x = synthetic_frames(n, seed=2016 + rank, device=f"cuda:{device}")
+        probs = torch.empty((n, m.topology.classes), dtype=torch.float32, device=x.device)
+        labels = torch.empty((n,), dtype=torch.int32, device=x.device)
+        chunk = launch_chunk(WORKLOADS[name][0], dtype, n)
+        m.bench_chunk = chunk      # (the untimed profiling pass of dominant_roofline launches the same way)
+        m.forward_device(x[: min(n, 4096)], probs=probs[: min(n, 4096)], labels=labels[: min(n, 4096)])     # library + weights are usable
+        if chunk:
+            m.reserve_workspace(chunk)      # the big allocation happens HERE, where a failure can still be agreed on
+        torch.cuda.synchronize()
+    except Exception as e:      # noqa: BLE001 -- reported below, on every rank
+        err = e
+    if dist:
+        try:
+            agree_ok(dist, err is None, name)
+        except LegSkipped:
+            if err is not None:
+                raise LegSkipped(f"{name}: {err!r}") from err
+            raise
+    elif err is not None:
+        raise err
     from modulationdetectioncnn_amd.sharding import timed_region
-    chunk = launch_chunk(WORKLOADS[name][0], dtype, n)
-    m.bench_chunk = chunk      # (the untimed profiling pass of dominant_roofline launches the same way)
     # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps, MAX over ranks
     el = timed_region(lambda: m.forward_device(x, probs=probs, labels=labels, batch_size=chunk), steps, warmup,
                       sync=torch.cuda.synchronize, device=x.device)
@@ -387,7 +424,52 @@ def select_device(device):
     torch.cuda.set_device(device)
 
 
-def main(argv=None):
+def self_launch(ngpu, argv, script):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the one-process-per-GPU job ourselves --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P <script> <argv>`
+    -- as a CHILD process (never exec: nothing here has touched the GPU, and nothing will in this parent), pass rank 0's
+    JSON line through on stdout and return the child's exit code.  Works the same under the driver's own launcher,
+    which sets WORLD_SIZE and never reaches this function."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpu}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    print(f"[bench] --gpus {ngpu} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in child.stdout:       # (the ranks' stderr goes straight through; their stdout carries rank 0's one line
+        if line.lstrip().startswith("{"):                   # and whatever a backend chats there, e.g. gloo's "[Gloo] Rank 0
+            lines += 1                                      # is connected ...": that goes to OUR stderr, so stdout is the line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        print(f"[bench] the {ngpu}-rank job printed {lines} JSON lines (expected 1)", file=sys.stderr)
+        return 3
+    return rc
+
+
+def compact_legs(out):
+    """{workload: [frames/s, roofline fraction]} of the headline and every extra leg that has a value -- a few hundred
+    bytes at the END of the line, so the per-config numbers survive a log that keeps only the tail."""
+    legs = {out["config"]["workload"]: [round(out["value"]), round(out["roofline"]["frac"], 4) if out.get("roofline") else None]}
+    for e in out.get("extra", []):
+        if isinstance(e, dict) and "value" in e and "workload" in e:
+            key = e["workload"] + (f" [{e['scaling']} x{e['n_gpus']}]" if "scaling" in e else "")
+            legs[key] = [round(e["value"]), round(e["roofline"]["frac"], 4) if isinstance(e.get("roofline"), dict) else None]
+    return legs
+
+
+def main(argv=None, script=None):
+    """script: the file the self-launched ranks run (default: this file; a wrapper that stubs the engine names itself)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -396,9 +478,20 @@ def main(argv=None):
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    launched = "WORLD_SIZE" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and not launched:
+        # however this file was invoked, --gpus N means N ranks: become the launcher's parent (BEFORE torch is imported)
+        return self_launch(args.gpus, sys.argv[1:] if argv is None else argv, script or os.path.abspath(__file__))
+    if args.gpus != world:
+        # never measure a different job than the one asked for and label it with a stderr note
+        print(f"[bench] --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: refusing to run", file=sys.stderr)
+        return 2
 
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -412,8 +505,6 @@ def main(argv=None):
     select_device(device)
     rank = dist.get_rank() if dist else 0
     ngpu = world if dist else 1
-    if args.gpus != ngpu and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={ngpu}: launch with torch.distributed.run", file=sys.stderr)
 
     name = args.workload
     kind, filters, classes, dtype, _, weights = WORKLOADS[name]
@@ -447,8 +538,8 @@ def main(argv=None):
                              "ms_per_step": lel / lsteps * 1e3, "steps": lsteps, "warmup": lwarm, "dtype": WORKLOADS[wl][3]})
                 del lm, lx, lp, ll
                 torch.cuda.empty_cache()
-            except Exception as e:      # an extra leg never hides the headline (every rank raises or none: same code path)
-                legs.append({"workload": wl, "reading": label, "error": repr(e)})
+            except LegSkipped as e:     # agreed on by every rank BEFORE the leg's collectives (run_workload): all skip together
+                legs.append({"workload": wl, "reading": label, "error": str(e)})
         if rank == 0:
             out["extra"] = legs
     if rank == 0 and ngpu == 1:
@@ -495,8 +586,14 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # the other BASELINE configs' numbers twice in compact form: inside `config` (a key every record keeps) and as the
+        # line's LAST key (a record that keeps only the tail of stdout still shows them)
+        legs = compact_legs(out)
+        out["config"]["legs_frames_per_s_and_roofline_frac"] = legs
+        out["legs"] = legs
+        print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

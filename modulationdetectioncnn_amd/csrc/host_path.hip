@@ -250,10 +250,17 @@ int run_pipeline(mdc_model* m, const char* src, int64_t n, int64_t chunk, bool r
     for (int64_t start = 0; start < n && rc == MDC_OK; start += count, ++i) {
         Slot& s = c->slot[i % kSlots];
         if ((rc = retire(s)) != MDC_OK) break;      // chunk i - 3 is done with the slot's buffers
-        const int64_t len = ramp && i < 2 ? std::max<int64_t>(256, (chunk >> (2 - i)) & ~(int64_t)255) : chunk;
+        // (never longer than a slot: with a large hop a slot holds fewer than 256 windows, and then there is no ramp)
+        const int64_t len = ramp && i < 2 ? std::min(chunk, std::max<int64_t>(256, (chunk >> (2 - i)) & ~(int64_t)255)) : chunk;
         count = std::min(len, n - start);
         size_t off = 0, bytes = 0;
         in_range(start, count, &off, &bytes);
+        if (count > c->out_cap || bytes > c->in_cap) {      // the slots were sized for `chunk`: refuse before any copy
+            set_error("host path: a chunk of %lld frames (%zu input bytes) exceeds its slot (%lld frames, %zu bytes)",
+                      (long long)count, bytes, (long long)c->out_cap, c->in_cap);
+            rc = MDC_EINVAL;
+            break;
+        }
         hipError_t e;
         if (direct) {
             e = hipMemcpyAsync(s.d_in, src + off, bytes, hipMemcpyHostToDevice, c->copy_s);

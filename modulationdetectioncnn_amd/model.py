@@ -66,6 +66,7 @@ class VTCNN2:
         self._weights: Optional[Weights] = None
         self._handle: Optional[C.c_void_p] = None
         self._ws = {}
+        self._ws_captured = []  # buffers whose address a captured hipGraph holds (never evicted; see _workspace)
         self._ws_need = {}      # frames per launch -> mdc_workspace_bytes (a property of the finalized model)
         # frames per mdc_forward call when the caller gives no batch_size.  VT-CNN2: the workspace holds one call's features
         # (21.6 KB/frame in the 16-bit modes, 42 KB at f32): 65,536 frames per call = 1.45 GB (f32: 2.8 GB) per stream, and
@@ -230,6 +231,7 @@ class VTCNN2:
             self._lib().mdc_destroy(self._handle)
             self._handle = None
         self._ws = {}
+        self._ws_captured = []
         self._ws_need = {}
 
     def __del__(self):
@@ -253,12 +255,28 @@ class VTCNN2:
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=f"cuda:{self.device_index}")
         self._ws[key] = ws                      # (dict order = recency: re-inserted at the end)
+        if torch.cuda.is_current_stream_capturing() and not any(w is ws for w in self._ws_captured):
+            # a hipGraph being captured bakes this buffer's ADDRESS into its kernel nodes: the buffer must outlive every
+            # replay, so neither the LRU below nor a later, larger chunk may hand it back to the allocator.
+            # It stays referenced here until release_captured_workspaces() / the model goes away.
+            self._ws_captured.append(ws)
         while len(self._ws) > self.MAX_WORKSPACES:
             # streams that are gone (worker threads' streams, a finished MultiStreamPredictor) do not pin HBM for ever:
             # the least recently used buffer goes back to torch's caching allocator, which keeps a block freed while
             # its stream still has work queued away from other streams until that work is done
             self._ws.pop(next(iter(self._ws)))
         return ws, need
+
+    def reserve_workspace(self, frames_per_call: int) -> int:
+        """Allocate (now, on torch's current stream) the scratch buffer a forward of `frames_per_call` frames per
+        mdc_forward call needs, so that the first timed / captured forward allocates nothing; returns its bytes."""
+        _ws, need = self._workspace(int(frames_per_call))
+        return need
+
+    def release_captured_workspaces(self) -> None:
+        """Drop the references that keep scratch buffers alive for captured hipGraphs.  Call only after every graph
+        captured from this model's forwards has been destroyed: a replay after this writes through a stale address."""
+        self._ws_captured = []
 
     # ------------------------------------------------------------------ inference
     def tap_shape(self, tap: str) -> Tuple[int, ...]:

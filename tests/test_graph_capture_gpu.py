@@ -61,3 +61,48 @@ def test_raw_iq_forward_is_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(p0, p1) and torch.equal(l0, l1)
+
+
+def test_a_captured_workspace_survives_eviction_and_growth():
+    """the graph holds the scratch buffer's ADDRESS.  Five other streams forwarding through the same model push
+    the capture stream's entry out of the per-stream LRU (MAX_WORKSPACES = 4), and a later, larger chunk replaces it;
+    the captured buffer must stay allocated (nobody else may be handed its memory) and the replay stay bit-identical."""
+    m = _model("vtcnn2", "bf16")
+    dev = torch.device("cuda:0")
+    n = 4096
+    x = synthetic_frames(n, seed=5, device="cuda:0")
+    probs = torch.empty((n, 11), dtype=torch.float32, device=dev)
+    labels = torch.empty((n,), dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        m.forward_device(x, probs, labels)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        m.forward_device(x, probs, labels)
+    assert len(m._ws_captured) == 1
+    held = m._ws_captured[0]
+    addr = held.data_ptr()
+    others = [torch.cuda.Stream(device=dev) for _ in range(5)]
+    for s in others:                                                  # evicts the capture stream's LRU entry
+        with torch.cuda.stream(s):
+            m.forward_device(x)
+    with torch.cuda.stream(side):                                     # a larger chunk on the capture stream replaces the entry
+        m.forward_device(synthetic_frames(3 * n, seed=9, device="cuda:0"), batch_size=3 * n)
+    torch.cuda.synchronize()
+    assert side.cuda_stream not in m._ws or m._ws[side.cuda_stream] is not held
+    assert m._ws_captured[0] is held and held.data_ptr() == addr      # still allocated, same address
+    # whatever the allocator hands out now must not alias the captured buffer
+    grab = [torch.full((held.numel(),), 0xAB, dtype=torch.uint8, device=dev) for _ in range(3)]
+    assert all(t.data_ptr() + t.numel() <= addr or t.data_ptr() >= addr + held.numel() for t in grab)
+    x.copy_(synthetic_frames(n, seed=6, device="cuda:0"))
+    probs.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    p_direct, l_direct, _ = m.forward_device(x)
+    torch.cuda.synchronize()
+    assert torch.equal(probs, p_direct) and torch.equal(labels, l_direct)
+    assert all(bool((t == 0xAB).all()) for t in grab)                 # the replay wrote nothing outside its own buffer
+    del g
+    m.release_captured_workspaces()
+    assert m._ws_captured == []

@@ -108,6 +108,24 @@ def test_host_iq_bytes_match_the_device_path(kind, hop):
         np.testing.assert_array_equal(l, want_l.cpu().numpy())
 
 
+@pytest.mark.parametrize("kind,hop,n", [("deployed3", 1 << 20, 128), ("deployed3", 1 << 18, 700), ("vtcnn2-bf16", 1 << 18, 520)])
+def test_host_iq_bytes_with_a_hop_so_large_that_a_slot_holds_fewer_than_256_windows(kind, hop, n):
+    """the library's own chunking cuts a slot to the windows that fit 64 MiB of capture (32 at hop 2^20,
+    128 at 2^18); with n >= 4 slots the fill ramp is on and its 256-window floor must not exceed the slot.  Results equal
+    the device path's bit for bit; the first window, the slot edges and the tail are all inside the compared range."""
+    m = VTCNN2.synthetic(Topology.vtcnn2(11), dtype="bf16") if kind == "vtcnn2-bf16" else _t1()
+    rng = np.random.default_rng(hop + n)
+    iq = np.zeros(2 * hop * (n - 1) + 256, dtype=np.uint8) + np.uint8(127)
+    for w in range(n):                                                     # only the bytes the windows read need entropy
+        iq[2 * hop * w: 2 * hop * w + 256] = rng.integers(0, 256, size=256, dtype=np.uint8)
+    scale = 0.02 / 127.5
+    want_p, want_l = m.predict_iq_u8(torch.from_numpy(iq).cuda(), scale=scale, hop=hop)
+    probs, labels = np.full((n, m.topology.classes), np.nan, np.float32), np.full((n,), -1, np.int32)
+    _cabi.check(_cabi.lib().mdc_predict_host_iq_u8(m._engine(), iq.ctypes.data, n, hop, scale, probs.ctypes.data, labels.ctypes.data, 0))
+    np.testing.assert_array_equal(probs, want_p.cpu().numpy())
+    np.testing.assert_array_equal(labels, want_l.cpu().numpy())
+
+
 def test_host_path_errors():
     m = _t1()
     L = _cabi.lib()

@@ -268,6 +268,96 @@ def test_bench_main_under_gloo_world2(tmp_path):
         assert leg["ms_per_step"] >= 40 * 0.9                         # MAX over ranks here too
 
 
+_STUB_WRAPPER = """
+import os, sys, time
+sys.path.insert(0, {root!r})
+import bench
+from modulationdetectioncnn_amd import Topology
+from modulationdetectioncnn_amd.sharding import timed_region
+
+
+class _Stub:
+    topology = Topology.vtcnn2(11)
+    dtype = "bf16"
+
+
+def run_workload(name, device, steps, warmup, dist=None, frames=None):
+    rank = dist.get_rank() if dist else 0
+    bench.agree_ok(dist, True, name)
+    el = timed_region(lambda: time.sleep(0.01 * (rank + 1)), steps, warmup)
+    return _Stub(), None, None, None, (2048 if frames is None else frames), el
+
+
+bench.run_workload = run_workload
+bench.select_device = lambda d: None
+bench.dominant_roofline = lambda *a, **k: ({{"bound": "mfma", "frac": 0.5}}, {{}})
+sys.exit(bench.main(script=os.path.abspath(__file__)))
+"""
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` typed at a shell (no torch.distributed.run around it, WORLD_SIZE
+    unset) must still be a 2-rank job: the parent starts the launcher as a child process and relays rank 0's ONE line."""
+    import json
+    import subprocess
+    wrapper = tmp_path / "bench_stub.py"
+    wrapper.write_text(_STUB_WRAPPER.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MDC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(wrapper), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["global_batch"] == 4096 and j["config"]["frames_per_gpu"] == 2048
+    assert j["ms_per_step"] >= 20 * 0.9                                # MAX over ranks: rank 1 sleeps 20 ms per step
+    assert [e["scaling"] for e in j["extra"]] == ["strong", "weak"]
+    # compact per-leg numbers, inside config and as the line's last key
+    assert list(j)[-1] == "legs" and j["legs"] == j["config"]["legs_frames_per_s_and_roofline_frac"]
+    assert j["legs"]["vtcnn2-c11-bf16-n2^20"] == [round(j["value"]), 0.5] and len(j["legs"]) == 3
+    assert "starting" in r.stderr and "torch.distributed.run" in r.stderr
+
+
+def test_bench_refuses_a_launcher_whose_world_size_disagrees(monkeypatch, capsys):
+    """... and never falls through to a run of another size labelled only by a note on stderr."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert bench.main(["--gpus", "8", "--no-extras", "--no-cpu-baseline"]) == 2
+    cap = capsys.readouterr()
+    assert cap.out == "" and "refusing" in cap.err
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert bench.main(["--gpus", "1"]) == 2
+
+
+def _skip_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo")
+    try:
+        bench.agree_ok(dist, True, "leg-a")                            # all fine: returns
+        try:
+            bench.agree_ok(dist, rank != 1, "leg-b")                   # rank 1 failed alone: EVERY rank raises
+            res = "ran"
+        except bench.LegSkipped as e:
+            res = "skipped:" + str(e)
+        dist.barrier()                                                 # the next leg's collectives still line up
+        with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+            f.write(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_leg_that_fails_on_one_rank_is_skipped_by_all(tmp_path):
+    """one rank's set-up failure (HBM shared with another job) must not leave its peers in the leg's barrier."""
+    mp.spawn(_skip_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = open(tmp_path / "r0.txt").read(), open(tmp_path / "r1.txt").read()
+    assert r0.startswith("skipped:") and r1.startswith("skipped:") and "(this one)" in r1 and "(this one)" not in r0
+
+
 def test_collective_device_follows_the_backend(monkeypatch):
     """under RCCL ("nccl") a CPU tensor must never reach a collective; under gloo it must stay on the host."""
     from modulationdetectioncnn_amd import sharding
