@@ -6,10 +6,16 @@
     per-SNR confusion matrices and acc[snr] = cor / (cor + ncor)          cnn.py:228-259 -> VTCNN2.accuracy_by_snr (one forward, one launch)
     cPickle.dump(("CNN2", 0.5, acc), open('results_cnn2_d0.5.dat','wb'))  cnn.py:262-264 -> VTCNN2.save_results
 
-The reference evaluates on RML2016.10a, which is not available here: the dataset below is synthetic and has
-the reference's shape -- a dict {(modulation, snr): (n, 2, 128) float32}, flattened the way cnn.py:42-75 flattens it.
+The reference evaluates on RML2016.10a, which is not available here: without --dataset the data below is
+synthetic and has the reference's shape -- a dict {(modulation, snr): (n, 2, 128) float32}, flattened the way cnn.py:42-75
+flattens it.  With the real file, the data half of cnn.py runs first (formats/rml2016.py: a no-code reader of the Python-2
+pickle, the cell selection of cnn.py:49-59, the seeded split of cnn.py:66-72) and the evaluation runs on its X_test:
 
     python examples/evaluate_like_cnn_py.py [weights.h5 | weights.npz] [results.dat]
+    python examples/evaluate_like_cnn_py.py weights.h5 results.dat --dataset RML2016.10a_dict.pkl \
+           [--mods WBFM,AM-SSB,GFSK] [--snrs 2,4,6,8,10,12,14,16,18] [--train-fraction 0.7] [--seed 2015]
+    (defaults: the 3-class selection, 70/30 split and seed 2015 of CNN.ipynb cells 2 and 4, which trained the bundled .h5 files;
+     cnn.py itself uses BPSK,GFSK,QAM16,QPSK,WBFM, 0.5 and seed 2016)
 """
 import os
 import sys
@@ -20,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from modulationdetectioncnn_amd import VTCNN2, synthetic_frames      # noqa: E402
+from modulationdetectioncnn_amd.formats import rml2016                # noqa: E402
 
 
 def synthetic_dataset(mods=("8PSK", "BPSK", "QAM16"), snrs=range(-4, 20, 2), per_cell=300, seed=7):
@@ -59,13 +66,34 @@ def evaluate(model, X_test, lbl, classes, batch_size=1024, results_path=None):
     return test_Y_hat, confnorm, acc, conf_by_snr
 
 
+def test_split_of(path, mods_chosen, snrs_chosen, train_fraction, seed):
+    """cnn.py:42-82 up to X_test: (X_test, lbl of the test frames, classes = mods_chosen)."""
+    ds = rml2016.RML2016.load(path)                                          # cnn.py:42-45
+    X, lbl = ds.select(mods_chosen, snrs_chosen)                             # cnn.py:49-59
+    _train_idx, test_idx = rml2016.split_indices(len(X), train_fraction, seed)   # cnn.py:66-72
+    return X[test_idx], [lbl[int(i)] for i in test_idx], list(mods_chosen)   # cnn.py:74, 80-82, 91
+
+
 def main(argv):
-    if len(argv) > 1 and argv[1].endswith(".h5"):
-        model = VTCNN2.from_h5(argv[1])
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("weights", nargs="?", default=os.path.join(ROOT, "tests", "golden", "weights", "3convmodrecnets_CNN2_0.5.npz"))
+    ap.add_argument("results", nargs="?", default=None)
+    ap.add_argument("--dataset", help="RML2016.10a_dict.dat / .pkl (not bundled with the reference)")
+    ap.add_argument("--mods", default="WBFM,AM-SSB,GFSK")
+    ap.add_argument("--snrs", default="2,4,6,8,10,12,14,16,18")
+    ap.add_argument("--train-fraction", type=float, default=0.7)
+    ap.add_argument("--seed", type=int, default=2015)
+    args = ap.parse_args(argv[1:])
+    model = VTCNN2.from_h5(args.weights) if args.weights.endswith(".h5") else VTCNN2.from_npz(args.weights)
+    if args.dataset:
+        X_test, lbl, classes = test_split_of(args.dataset, args.mods.split(","), [int(s) for s in args.snrs.split(",")],
+                                             args.train_fraction, args.seed)
+        if len(classes) != model.topology.classes:
+            raise SystemExit(f"{len(classes)} modulations chosen but the model has {model.topology.classes} classes")
     else:
-        model = VTCNN2.from_npz(argv[1] if len(argv) > 1 else os.path.join(ROOT, "tests", "golden", "weights", "3convmodrecnets_CNN2_0.5.npz"))
-    X_test, lbl, classes = flatten(synthetic_dataset())
-    _, confnorm, acc, _ = evaluate(model, X_test, lbl, classes, results_path=argv[2] if len(argv) > 2 else None)
+        X_test, lbl, classes = flatten(synthetic_dataset())
+    _, confnorm, acc, _ = evaluate(model, X_test, lbl, classes, results_path=args.results)
     np.set_printoptions(precision=3, suppress=True)
     print(confnorm)
     print(classes)

@@ -7,6 +7,8 @@ Reads (never executes) under /root/reference:
   * the seven Q6.12 weight .txt files          -> golden/weights_txt/<name>.npz
   * CNN.ipynb cell 18 stored output (text)     -> golden/keras_kat.json  (float input + Keras answer)
   * the "* prediction:" comments of 12.16.testDataYunyun.txt -> frames.json
+  * the three stored model.summary() printouts (CNN.ipynb cell 6 = T1, cnn.ipynb = T4, the DeepSig notebook = T3)
+                                               -> golden/summaries.json (layer kinds, output shapes, parameter counts)
 
 Everything written is derived data (arrays / numbers); no reference source text is copied.
 Oracle-derived expectations (labels frozen per SURVEY.md 8(c)(5)) are written by
@@ -50,6 +52,41 @@ def cell18():
     pred = [float(t) for t in re.findall(r"-?\d+\.\d+", tail)]
     assert len(pred) == 3, pred
     return np.asarray(nums, np.float32).reshape(1, 2, 128), pred, cell.get("execution_count")
+
+
+SUMMARIES = {      # topology tag -> (notebook, how the build names it)
+    "deployed3": "CNN.ipynb",
+    "cnnpy": "cnn.ipynb",
+    "vtcnn2": "examples-master/modulation_recognition/RML2016.10a_VTCNN2_example.ipynb",
+}
+_ROW = re.compile(r"^\S+\s+\((\w+)\)?\s+\((None(?:,\s*\d+)+)\)\s+(\d+)")
+
+
+def stored_summaries():
+    """The model.summary() tables Keras printed into the notebooks' stored outputs: per layer the class name (as
+    printed: Keras 2 truncates "ZeroPadding2D" to "ZeroPaddin"), the output shape without the batch axis and the
+    parameter count; plus the "Total params" line.  Numerals and class names only -- no notebook text is kept."""
+    out = {}
+    for tag, rel in SUMMARIES.items():
+        nb = json.load(open(os.path.join(REF, rel)))
+        found = None
+        for ci, cell in enumerate(nb["cells"]):
+            for o in cell.get("outputs", []):
+                text = "".join(o.get("text", ""))
+                if "Layer (type)" in text and "Total params" in text:
+                    found = (ci, text)
+        assert found, rel
+        ci, text = found
+        layers = []
+        for line in text.splitlines():
+            m = _ROW.match(line)
+            if m:
+                layers.append({"class": m.group(1), "output_shape": [int(t) for t in m.group(2).split(",")[1:]],
+                               "params": int(m.group(3))})
+        total = int(re.search(r"Total params:\s*([\d,]+)", text).group(1).replace(",", ""))
+        assert sum(l["params"] for l in layers) == total, (tag, total)
+        out[tag] = {"source": f"{rel} cell {ci} stored output (model.summary())", "layers": layers, "total_params": total}
+    return out
 
 
 def main():
@@ -99,6 +136,7 @@ def main():
                "input": [float(np.float32(v)) for v in x.ravel()], "keras_dense": pred},
               open(os.path.join(OUT, "keras_kat.json"), "w"))
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+    json.dump(stored_summaries(), open(os.path.join(OUT, "summaries.json"), "w"), indent=1)
     print("wrote", OUT)
 
 
