@@ -33,9 +33,12 @@
 extern "C" {
 #endif
 
-#define MDC_ABI_VERSION 3   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows
+#define MDC_ABI_VERSION 4   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows
                                3: mdc_topology.reserved[0] is a validated option word (no bit defined: must be 0);
-                                  mdc_iq_u8_windows wants 2-byte aligned input; the library reads no environment */
+                                  mdc_iq_u8_windows wants 2-byte aligned input; the library reads no environment
+                               4: MDC_KIND_VTCNN2 at MDC_FP8 keeps E4M3 features (its workspace per frame shrinks from
+                                  22,144 to 11,584 bytes: ask mdc_workspace_bytes); MDC_OPT_FP8_BF16_FEATURES restores
+                                  ABI 3's numerics and workspace */
 
 /* error codes (negative errno values) */
 #define MDC_OK        0
@@ -68,7 +71,8 @@ enum {
  * activations of 2^32 and beyond saturate there instead of growing on (tests/test_deployed_gpu.py pins it).
  * MDC_F16: MDC_KIND_DEPLOYED only -- as MDC_BF16 there, with IEEE f16 operands and the conv itself in packed f16
  * (11 significant bits instead of 8, but conv outputs must stay below 65,504).
- * MDC_FP8: MDC_KIND_VTCNN2 -- conv2 on the block-scaled e4m3 MFMA (conv1 and dense1 as in MDC_BF16) -- and
+ * MDC_FP8: MDC_KIND_VTCNN2 -- conv2 on the block-scaled e4m3 MFMA, its features handed to dense1 as E4M3 bytes (conv1
+ * and dense1's arithmetic as in MDC_BF16; see MDC_OPT_FP8_BF16_FEATURES) -- and
  * MDC_KIND_DEPLOYED -- as MDC_BF16 there with e4m3 operands (BASELINE configs[4] read literally); the activations are
  * scaled for the largest |sample| given with mdc_set_fp8_input_absmax -- beyond it they saturate. */
 enum { MDC_F32 = 0, MDC_BF16 = 1, MDC_FP8 = 2, MDC_F16 = 3 };
@@ -90,10 +94,16 @@ typedef struct mdc_topology {
     int32_t reserved[4]; /* [0]: option bits MDC_OPT_* (0 = defaults); [1..3] must be 0      */
 } mdc_topology;
 
-/* Option bits (mdc_topology.reserved[0]; validated by mdc_create, fixed for the model's life).  None is defined: every
- * kernel evaluates the layers in Keras' operation order (round 2's re-associated conv of the 10-filter net and the bit
- * that switched it off are gone: the ReLU now rides in the fma's clamp bit, which is faster AND exact). */
-#define MDC_OPT_ALL 0
+/* Option bits (mdc_topology.reserved[0]; validated by mdc_create, fixed for the model's life).  Every kernel evaluates
+ * the layers in Keras' operation order whatever the bits say (round 2's re-associated conv of the 10-filter net and the
+ * bit that switched it off are gone: the ReLU now rides in the fma's clamp bit, which is faster AND exact).
+ * MDC_OPT_FP8_BF16_FEATURES (MDC_KIND_VTCNN2, honoured at MDC_FP8 only, refused at any other dtype): keep the conv2
+ * features between the conv kernel and dense1 in bf16, as the library did up to ABI 3.  Default since ABI 4: E4M3 bytes
+ * with one power-of-two scale per tensor (half the feature traffic of both kernels; dense1 converts them back to bf16
+ * exactly and keeps bf16 weights, so only the features' own rounding -- 3 significant bits + hidden one instead of
+ * 7 + 1 -- changes: tests/test_label_agreement_gpu.py holds the same label floors for both). */
+#define MDC_OPT_FP8_BF16_FEATURES 1
+#define MDC_OPT_ALL 1
 
 typedef struct mdc_model mdc_model;   /* opaque, owned by the library */
 

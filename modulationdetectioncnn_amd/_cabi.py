@@ -26,7 +26,8 @@ EXPORTS = [
     "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax",
     "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
+MDC_OPT_FP8_BF16_FEATURES = 1      # include/mdc.h: option bit in mdc_topology.reserved[0]
 HOP_FRAME = 128
 
 

@@ -123,6 +123,10 @@ int mdc_create(const mdc_topology* topo, int device, mdc_model** out) {
         *out = nullptr;
         if ((topo->reserved[0] & ~MDC_OPT_ALL) != 0) { set_error("mdc_create: unknown option bits 0x%x in reserved[0]", topo->reserved[0]); return MDC_EINVAL; }
         for (int i = 1; i < 4; ++i) if (topo->reserved[i] != 0) { set_error("mdc_create: reserved[1..3] must be 0"); return MDC_EINVAL; }
+        if ((topo->reserved[0] & MDC_OPT_FP8_BF16_FEATURES) && topo->kind != MDC_KIND_VTCNN2) {
+            set_error("mdc_create: MDC_OPT_FP8_BF16_FEATURES applies to MDC_KIND_VTCNN2 only");
+            return MDC_EINVAL;
+        }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MDC_ENODEV; }
         if (device < 0 || device >= ndev) { set_error("device %d out of range (have %d)", device, ndev); return MDC_ENODEV; }
@@ -195,6 +199,7 @@ int mdc_finalize(mdc_model* m, int dtype) {
         if (dtype != MDC_F32 && dtype != MDC_BF16 && dtype != MDC_FP8 && dtype != MDC_F16) { set_error("unknown dtype %d", dtype); return MDC_EINVAL; }
         if (dtype == MDC_F16 && m->topo.kind != MDC_KIND_DEPLOYED) { set_error("f16 is implemented for the deployed nets only"); return MDC_ENOTSUP; }
         if (dtype == MDC_FP8 && m->topo.kind == MDC_KIND_CNNPY) { set_error("fp8 is implemented for the vtcnn2 and deployed families only"); return MDC_ENOTSUP; }
+        if ((m->topo.reserved[0] & MDC_OPT_FP8_BF16_FEATURES) && dtype != MDC_FP8) { set_error("mdc_finalize: MDC_OPT_FP8_BF16_FEATURES is an option of the MDC_FP8 mode"); return MDC_EINVAL; }
         if (dtype == MDC_BF16 && m->topo.kind == MDC_KIND_CNNPY) { set_error("bf16 is implemented for the vtcnn2 and deployed families only"); return MDC_ENOTSUP; }
         m->dtype = dtype;
         DeviceScope dev(m->device);      // uploads go to the model's device; the caller's current device is restored

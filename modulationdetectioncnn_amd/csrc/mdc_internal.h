@@ -46,6 +46,18 @@ __host__ __device__ constexpr int feat16_index(int w, int o) {
     return (w >> 1) * (2 * kC2) + (o < 64 ? (w & 1) * 64 + o : 128 + 2 * (o - 64) + (w & 1));
 }
 
+// Feature row of the fp8 mode's E4M3 features (round 4; one byte per element, one power-of-two scale per tensor): output
+// positions in GROUPS OF FOUR of 320 bytes --
+//   [pair (w0, w1): sixteen 8-byte slots {4 channels of w0, the same 4 channels of w1}]  128 B, channels 0..63
+//   [pair (w2, w3): the same]                                                            128 B
+//   [channels 64..79, each as the bytes (w0, w1, w2, w3)]                                 64 B
+// so that the fp8 conv kernel's finishing lanes store one dwordx2 per position PAIR (their four channels of both
+// positions) and one dword per GROUP (their fifth-tile channel of all four) -- no store at all on even steps.  As with
+// feat16_index the order of K is dense1's to choose: its weight rows are permuted with this function at pack time.
+__host__ __device__ constexpr int feat8_index(int w, int o) {
+    return (w >> 2) * (4 * kC2) + (o < 64 ? ((w >> 1) & 1) * 128 + 8 * (o >> 2) + 4 * (w & 1) + (o & 3) : 256 + 4 * (o - 64) + (w & 3));
+}
+
 // 8 raw bytes from an address that is only 2-byte aligned (a window of a uint8 I/Q capture at an arbitrary hop):
 // gfx950 global loads take unaligned addresses, and hipcc emits ONE global_load_dwordx2 for this
 __device__ __forceinline__ uint2 load8_unaligned(const unsigned char* p) {
@@ -93,6 +105,8 @@ struct mdc_model {
     int alt_ring = -1;           // alternates build, MDC_DEP_RING=N: ring depth of the 3-filter f32 kernel (0 = direct loads); -1 = the product's choice
     float fp8_input_absmax = 0.02f;
     int fp8_feat_scale_log2 = 0;
+    bool fp8_e4m3_features = false;   // vtcnn2 at MDC_FP8 without MDC_OPT_FP8_BF16_FEATURES: the workspace features are E4M3 bytes (x 2^feat_scale_log2)
+    float fp8_feat_divisor = 1.f;     // ... and this is what the conv kernel's finish divides its sums (true x 2^-32) by before rounding them
     int feat_scale_log2 = 0;     // 16-bit modes: the workspace features are the true ones times 2^feat_scale_log2 (taps undo it)
 
     // profiling is the one piece of state mdc_forward touches on a finalized model: the event lists are guarded, so

@@ -316,6 +316,20 @@ __global__ void vt_unpermute_kernel(const T* __restrict__ feat, long n, float* _
     }
 }
 
+// E4M3 features (fp8 mode): feat[f][feat8_index(w, o)], one byte each, true value x 2^k -> the same reference layout
+__global__ void vt_unpermute8_kernel(const unsigned char* __restrict__ feat, long n, float* __restrict__ out, float unscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * kFeat) return;
+    const long f = i / kFeat;
+    const int r = (int)(i % kFeat);
+    const int o = r / kW2, w = r % kW2;
+    const unsigned v = feat[f * kFeat + feat8_index(w, o)];
+    const int e = (int)((v >> 3) & 15u), mant = (int)(v & 7u);      // OCP E4M3: bias 7, subnormals at e = 0, 0x7F / 0xFF = NaN
+    float mag = e == 0 ? ldexpf((float)mant, -9) : ldexpf(1.f + (float)mant * 0.125f, e - 7);
+    if ((v & 0x7Fu) == 0x7Fu) mag = __uint_as_float(0x7FC00000u);
+    out[i] = ((v & 0x80u) ? -mag : mag) * unscale;                   // exact (a power of two)
+}
+
 }  // namespace
 
 // ---- dense_chain.hip: Dense(C) + softmax + first-max argmax of the head -----------------
@@ -383,7 +397,8 @@ int vtcnn2_pack(mdc_model* m) {
     return upload(m, 3, w1p.data(), w1p.size() * sizeof(float));
 }
 
-static size_t feat_elem(const mdc_model* m) { return m->dtype == MDC_F32 ? 4 : 2; }      // bf16 features in bf16 and fp8 modes
+// bytes per feature: f32; bf16 in the bf16 mode (and in the fp8 mode under MDC_OPT_FP8_BF16_FEATURES); E4M3 in the fp8 mode
+static size_t feat_elem(const mdc_model* m) { return m->dtype == MDC_F32 ? 4 : (m->dtype == MDC_FP8 && m->fp8_e4m3_features) ? 1 : 2; }
 
 size_t vtcnn2_workspace_bytes(const mdc_model* m, int64_t n) {
     const size_t np = ((size_t)n + 255) & ~(size_t)255;   // kernels write whole 16-frame groups / 256-row tiles
@@ -456,7 +471,9 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
         const long total = (long)n * kFeat;
         // fp8 mode keeps its features multiplied by a power of two (dense1's weights carry the inverse)
         const float unscale = std::ldexp(1.f, -m->feat_scale_log2);      // the 16-bit modes keep their features times a power of two
-        if (m->dtype != MDC_F32)
+        if (feat_elem(m) == 1)
+            hipLaunchKernelGGL(vt_unpermute8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned char*>(feat), (long)n, tap, unscale);
+        else if (m->dtype != MDC_F32)
             hipLaunchKernelGGL(vt_unpermute_kernel<unsigned short>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned short*>(feat), (long)n, tap, unscale);
         else
             hipLaunchKernelGGL(vt_unpermute_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(feat), (long)n, tap, unscale);

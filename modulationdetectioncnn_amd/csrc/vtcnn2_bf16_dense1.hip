@@ -6,6 +6,14 @@
 //                                 __syncthreads per K-tile.  Simple; LDS-DMA issue + fragment reads and the MFMAs do
 //                                 not overlap (tools/ablate_dense1.py).  Kept as the race screen (MDC_DENSE1_PHASED=0).
 //   vt_dense1_bf16_phased_kernel  the production kernel; see the comment above it.
+//
+// Round 4, F8 = true (the fp8 mode's default): the feature matrix holds E4M3 bytes (one power-of-two scale per tensor,
+// feat8_index order; vtcnn2_fp8_conv.hip) -- half the bytes of dense1's HBM stream, which is what bounds it.  The MFMA
+// stays v_mfma_f32_16x16x32_bf16 with bf16 weights (e4m3 WEIGHTS miss a label floor, profiles/r03_exp_fp8_features.json):
+// a feature fragment is 8 bytes per lane (ds_read_b64 / global_load_dwordx2) and becomes the bf16x8 operand through four
+// v_cvt_scalef32_pk_bf16_fp8 (x 1.0: exact; tools/microbench/cvt_bf16_fp8_probe.hip) -- 64 VALU per wave and K-tile next
+// to 64 MFMAs of 16 cycles.  Every form (batch, per-wave, four-wave ring) converts the same bytes to the same operands
+// and keeps the K order, so they stay bit-identical to each other.
 #include "vtcnn2_bf16_common.h"
 #include "dense_chain_common.h"
 
@@ -24,6 +32,17 @@ constexpr size_t kDenseBf16Lds = (size_t)4 * kTileBytes;      // A,B x 2 buffers
 constexpr size_t kDenseHeadLds = (size_t)128 * kChainXld * 4;  // fused head: [128 rows][260] f32 image of a wave row's hidden tile (133,120 B)
 static_assert(kDenseHeadLds >= kDenseBf16Lds, "the fused-head form allocates the larger of the two");
 constexpr int kNT = kFeat / kBK;                              // 165 K-tiles
+
+// 8 E4M3 bytes (k ascending) -> the bf16x8 MFMA operand; x 1.0, exact
+__device__ __forceinline__ bf16x8 cvt_e4m3x8(u32x2 r) {
+    u32x4 o;
+    const float one = 1.0f;
+    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2" : "=v"(o[0]) : "v"(r[0]), "v"(one));
+    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(o[1]) : "v"(r[0]), "v"(one));
+    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2" : "=v"(o[2]) : "v"(r[1]), "v"(one));
+    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(o[3]) : "v"(r[1]), "v"(one));
+    return __builtin_bit_cast(bf16x8, o);
+}
 
 
 #if defined(MDC_ALTERNATES) || defined(MDC_ABLATIONS)      // the race screen of the phased kernel: test / probe builds only
@@ -210,7 +229,13 @@ constexpr int kUnitBytes = 128 * 128;      // 128 rows x 64 bf16
 // LDS in the head kernel's [row][260] image and every wave runs the head's own 64-step v_mfma_f32_16x16x4_f32 chain and
 // softmax code (dense_chain_common.h) on one 16-row tile -- same operands, same order, same bits as the separate launch;
 // the 1 KiB/frame hidden layer is then neither written to HBM nor read back.
-template <int ABL, bool HEAD = false>   // ABL 0 = product; 1 = timing-only probe: every work-group streams the same A rows (L2 hits)
+// F8 (round 4): the A units hold E4M3 bytes -- 128 rows x 64 B = 8 KiB, ONE LDS-DMA instruction per wave (16 rows x 64 B:
+// lane l -> row l>>2, 16-byte chunk (l&3) ^ ((row>>2)&3) of the source, so that the ds_read_b64 fragment reads of 16 rows
+// x 2 halves spread over all 64 banks); the units keep their 16-KiB slots.  With 1 + 2 + 2 + 1 copies per K-tile
+// the counted waits become vmcnt(2) / (3) / (4) / (3) (last tile: (1) / (0)): phase p still retires exactly the unit the
+// next phase reads.  The raw fragments (ra) are converted once, right after their wait: a1 in phase 2 before its first
+// quadrant, the next tile's a0 at the end of phase 3 under that phase's MFMAs.
+template <int ABL, bool HEAD = false, bool F8 = false>   // ABL 0 = product; 1 = timing-only probe: every work-group streams the same A rows (L2 hits)
 __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsigned short* __restrict__ feat, long n,
                                                                     const unsigned short* __restrict__ w1t,   // [165][256][64]
                                                                     const float* __restrict__ c1, float* __restrict__ hid,
@@ -240,8 +265,26 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         src[1][j] = w1t + brow_lo * kBK + sw;
         src[2][j] = w1t + (brow_lo + 32) * kBK + sw;
     }
+    const unsigned char* src8[2] = {nullptr, nullptr};      // F8: [a0 unit, a1 unit], one 16-row piece per wave
+    if constexpr (F8) {
+        const int u = wv * 16 + (lane >> 2);                   // unit row 0..127
+        const int sw = ((lane & 3) ^ ((u >> 2) & 3)) * 16;     // swizzled source chunk (bytes)
+        const int arow_lo = 128 * (u >> 6) + (u & 63);
+        long g0 = row0 + arow_lo, g3 = row0 + arow_lo + 64;
+        if (g0 >= n) g0 = n - 1;
+        if (g3 >= n) g3 = n - 1;
+        const unsigned char* f8 = reinterpret_cast<const unsigned char*>(feat);
+        src8[0] = f8 + g0 * (long)kFeat + sw;
+        src8[1] = f8 + g3 * (long)kFeat + sw;
+    }
     auto stage_unit = [&](int t, int unit, int b) {
         unsigned char* dst = smem + ((size_t)b * 4 + unit) * kUnitBytes + (wv * 2) * 1024;
+        if constexpr (F8) {
+            if (unit == 0 || unit == 3) {      // E4M3 feature rows: 64 B per row and K-tile, one piece per wave
+                glds16_nt(src8[unit == 3] + (long)t * kBK, smem + ((size_t)b * 4 + unit) * kUnitBytes + wv * 1024);
+                return;
+            }
+        }
         if (unit == 0 || unit == 3) {      // feature rows: read once, non-temporal
             glds16_nt(src[unit][0] + (long)t * kBK, dst);
             glds16_nt(src[unit][1] + (long)t * kBK, dst + 1024);
@@ -262,13 +305,32 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+    u32x2 ra[4][2];      // F8: a unit's raw fragments between the ds_read_b64 and the conversion
 
     auto read_a = [&](bf16x8 (&a)[4][2], int unit, int b) {
         const unsigned char* base = smem + ((size_t)b * 4 + unit) * kUnitBytes;
+        if constexpr (F8) {      // row u (64 B), bytes 32 ks + 8 fg .. +7: chunk (2 ks + fg/2) ^ ((u>>2)&3), half fg & 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a[i][ks] = frag(base, 64 * wr + 16 * i + fr, ks);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int u = 64 * wr + 16 * i + fr;
+                    ra[i][ks] = *reinterpret_cast<const u32x2*>(base + u * 64 + (((ks * 2 + (fg >> 1)) ^ ((u >> 2) & 3)) * 16) + (fg & 1) * 8);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[i][ks] = frag(base, 64 * wr + 16 * i + fr, ks);
+        }
+    };
+    auto cvt_a = [&](bf16x8 (&a)[4][2]) {      // F8 only, after the lgkmcnt wait that covers ra
+        if constexpr (F8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[i][ks] = cvt_e4m3x8(ra[i][ks]);
+        }
     };
     auto read_b = [&](bf16x8 (&bq)[2][2], int unit, int b) {
         const unsigned char* base = smem + ((size_t)b * 4 + unit) * kUnitBytes;
@@ -302,6 +364,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
     for (int u = 0; u < 4; ++u) stage_unit(0, u, 0);
     D1_WAIT_BARRIER(0);
     read_a(a0, 0, 0);
+    if constexpr (F8) { D1_LGKM(); cvt_a(a0); }
 #ifndef D1_NOSTAGGER
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs half a phase behind
 #endif
@@ -319,7 +382,8 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         if (more) stage_unit(t + 1, 0, b ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         read_b(b0, 1, b);
-        if (more) D1_WAIT_BARRIER(4); else D1_WAIT_BARRIER(2);
+        if constexpr (F8) { if (more) D1_WAIT_BARRIER(2); else D1_WAIT_BARRIER(1); }
+        else { if (more) D1_WAIT_BARRIER(4); else D1_WAIT_BARRIER(2); }
         D1_LGKM();
         quadrant(a0, b0, 0, 0);
         __builtin_amdgcn_s_barrier();
@@ -327,7 +391,8 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         if (more) stage_unit(t + 1, 1, b ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         read_b(b1, 2, b);
-        if (more) D1_WAIT_BARRIER(4); else D1_WAIT_BARRIER(0);
+        if constexpr (F8) { if (more) D1_WAIT_BARRIER(3); else D1_WAIT_BARRIER(0); }
+        else { if (more) D1_WAIT_BARRIER(4); else D1_WAIT_BARRIER(0); }
         D1_LGKM();
         quadrant(a0, b1, 0, 2);
         __builtin_amdgcn_s_barrier();
@@ -337,15 +402,18 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         read_a(a1, 3, b);
         if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier();
         D1_LGKM();
+        cvt_a(a1);
         quadrant(a1, b1, 4, 2);
         __builtin_amdgcn_s_barrier();
         // phase 3: quadrant (a1, b0); a0 of tile t+1
         if (more) stage_unit(t + 1, 3, b ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         if (more) read_a(a0, 0, b ^ 1);
-        if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier();
+        if constexpr (F8) { if (more) D1_WAIT_BARRIER(3); else __builtin_amdgcn_s_barrier(); }
+        else { if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier(); }
         quadrant(a1, b0, 4, 0);
         D1_LGKM();
+        if (more) cvt_a(a0);
         __builtin_amdgcn_s_barrier();
     }
 #ifndef D1_NOSTAGGER
@@ -526,6 +594,8 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_wreg_kernel(const unsigned
 // 16 x ceil(n/16) waves on as many CUs share the layer.  Same instruction (v_mfma_f32_16x16x32_bf16), same fragment
 // contents and the same K order per output element as the tiled kernels: bit-identical results.
 // ------------------------------------------------------------------------------------
+// F8: the feature fragment is the lane's 8 E4M3 bytes (global_load_dwordx2), converted in front of its MFMA
+template <bool F8>
 __global__ __launch_bounds__(64) void vt_dense1_bf16_small_kernel(const unsigned short* __restrict__ feat, long n,
                                                                   const unsigned short* __restrict__ w1t,   // [165 k-tiles][256][64] bf16
                                                                   const float* __restrict__ c1, float* __restrict__ hid) {
@@ -534,28 +604,35 @@ __global__ __launch_bounds__(64) void vt_dense1_bf16_small_kernel(const unsigned
     const int col0 = blockIdx.y * 16;
     long ar = row0 + fr;
     if (ar >= n) ar = n - 1;                                  // rows past the end are computed, not stored
-    const unsigned short* ap = feat + ar * (long)kFeat + fg * 8;
+    using AFrag = typename std::conditional<F8, u32x2, bf16x8>::type;
+    // element pointer: bf16 elements, or bytes (F8: kFeat bytes per row, 8 per fragment)
+    const unsigned char* ap = reinterpret_cast<const unsigned char*>(feat) + (ar * (long)kFeat + fg * 8) * (F8 ? 1 : 2);
     const unsigned short* bp = w1t + (long)(col0 + fr) * kBK + fg * 8;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     // software pipeline over blocks of kU K-tiles, two register sets: the 20 fragment loads of block i+1 are in flight
     // while the 10 MFMAs of block i issue (the MFMA chain is the same: K-tiles in ascending order into one accumulator)
     constexpr int kU = 5, kBlocks = kNT / kU;
     static_assert(kNT % kU == 0 && kBlocks % 2 == 1, "blocks: an even count in the loop, the last one drained after it");
-    bf16x8 a0[kU][2], b0[kU][2], a1[kU][2], b1[kU][2];
-    auto load = [&](bf16x8 (&af)[kU][2], bf16x8 (&bfr)[kU][2], int blk) {
+    AFrag a0[kU][2], a1[kU][2];
+    bf16x8 b0[kU][2], b1[kU][2];
+    auto load = [&](AFrag (&af)[kU][2], bf16x8 (&bfr)[kU][2], int blk) {
 #pragma unroll
         for (int u = 0; u < kU; ++u)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                af[u][ks] = *reinterpret_cast<const bf16x8*>(ap + (blk * kU + u) * kBK + ks * 32);
+                af[u][ks] = *reinterpret_cast<const AFrag*>(ap + ((blk * kU + u) * kBK + ks * 32) * (F8 ? 1 : 2));
                 bfr[u][ks] = *reinterpret_cast<const bf16x8*>(bp + (long)(blk * kU + u) * (kBN * kBK) + ks * 32);
             }
     };
-    auto mma = [&](const bf16x8 (&af)[kU][2], const bf16x8 (&bfr)[kU][2]) {
+    auto mma = [&](const AFrag (&af)[kU][2], const bf16x8 (&bfr)[kU][2]) {
 #pragma unroll
         for (int u = 0; u < kU; ++u)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][ks], bfr[u][ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a;
+                if constexpr (F8) a = cvt_e4m3x8(af[u][ks]); else a = af[u][ks];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[u][ks], acc, 0, 0, 0);
+            }
     };
     load(a0, b0, 0);
     for (int blk = 0; blk < kBlocks - 1; blk += 2) {
@@ -589,6 +666,10 @@ constexpr int kRing = 24;                  // K-tiles in the ring
 constexpr int kGrp = 4;                    // K-tiles per step (one counted wait + one barrier per step)
 constexpr size_t kCoopLds = (size_t)kRing * 4096;
 
+// F8: a K-tile's feature fragment pair is ONE KiB (16 rows x 64 E4M3 bytes): wave 0 copies it (lane (fr, c) the 16-byte
+// chunk c of row fr), wave 1 copies nothing, and a reading lane takes its 8 bytes -- k = 32 ks + 8 fg .. +7 = chunk
+// 2 ks + fg/2, half fg & 1 -- with a ds_read_b64 and converts them in front of the MFMA.
+template <bool F8>
 __global__ __launch_bounds__(256) void vt_dense1_bf16_coop_kernel(const unsigned short* __restrict__ feat, long n,
                                                                   const unsigned short* __restrict__ w1t,   // [165 k-tiles][256][64] bf16
                                                                   const float* __restrict__ c1, float* __restrict__ hid) {
@@ -600,8 +681,17 @@ __global__ __launch_bounds__(256) void vt_dense1_bf16_coop_kernel(const unsigned
     long ar = row0 + fr;
     if (ar >= n) ar = n - 1;                                  // rows past the end are computed, not stored
     // this wave's fragment: A (wv = 0, 1) or B (wv = 2, 3), k half wv & 1; per-lane source as in the per-wave kernel
-    const unsigned short* src = (wv < 2 ? feat + ar * (long)kFeat : w1t + (long)(col0 + fr) * kBK) + fg * 8 + (wv & 1) * 32;
-    const long kstep = wv < 2 ? (long)kBK : (long)kBN * kBK;
+    // (byte pointers: F8 feature rows are kFeat BYTES long and wave 0 moves both k halves, see above)
+    const unsigned char* src;
+    long kstep;
+    if (wv < 2) {
+        if constexpr (F8) { src = reinterpret_cast<const unsigned char*>(feat) + ar * (long)kFeat + fg * 16; kstep = kBK; }
+        else { src = reinterpret_cast<const unsigned char*>(feat + ar * (long)kFeat + fg * 8 + (wv & 1) * 32); kstep = 2L * kBK; }
+    } else {
+        src = reinterpret_cast<const unsigned char*>(w1t + (long)(col0 + fr) * kBK + fg * 8 + (wv & 1) * 32);
+        kstep = 2L * kBN * kBK;
+    }
+    const bool copies = !(F8 && wv == 1);
     static_assert(kRing % kGrp == 0, "groups do not straddle the ring's end");
     constexpr int kAhead = kRing / kGrp - 1;                 // groups in flight
     constexpr int kGroups = kNT / kGrp, kTail = kNT - kGroups * kGrp;      // 41 full groups + 1 tile
@@ -609,23 +699,37 @@ __global__ __launch_bounds__(256) void vt_dense1_bf16_coop_kernel(const unsigned
 #pragma unroll
         for (int j = 0; j < kGrp; ++j) {
             const int t = g * kGrp + j, tc = t < kNT ? t : kNT - 1;
-            glds16_async(src + tc * kstep, smem + (size_t)(t % kRing) * 4096 + wv * 1024);
+            if (copies) glds16_async(src + tc * kstep, smem + (size_t)(t % kRing) * 4096 + wv * 1024);
         }
     };
     auto read = [&](bf16x8 (&f)[kGrp][4], int g) {
-        const unsigned char* base = smem + (size_t)((g * kGrp) % kRing) * 4096 + lane * 16;
+        const unsigned char* slot = smem + (size_t)((g * kGrp) % kRing) * 4096;
+        const unsigned char* base = slot + lane * 16;
 #pragma unroll
         for (int j = 0; j < kGrp; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) f[j][q] = *reinterpret_cast<const bf16x8*>(base + j * 4096 + q * 1024);
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (F8) {
+                    if (q < 2) {      // raw bytes in the low half of the register set; converted in mma()
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(slot + j * 4096 + (fr + 16 * (2 * q + (fg >> 1))) * 16 + (fg & 1) * 8);
+                        f[j][q] = __builtin_bit_cast(bf16x8, u32x4{r[0], r[1], 0u, 0u});
+                        continue;
+                    }
+                }
+                f[j][q] = *reinterpret_cast<const bf16x8*>(base + j * 4096 + q * 1024);
+            }
     };
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto afrag = [&](const bf16x8& raw) {
+        if constexpr (F8) { const u32x4 r = __builtin_bit_cast(u32x4, raw); return cvt_e4m3x8(u32x2{r[0], r[1]}); }
+        else return raw;
+    };
     auto mma = [&](const bf16x8 (&f)[kGrp][4], int tiles) {
 #pragma unroll
         for (int j = 0; j < kGrp; ++j)
             if (j < tiles) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j][0], f[j][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j][1], f[j][3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag(f[j][0]), f[j][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag(f[j][1]), f[j][3], acc, 0, 0, 0);
             }
     };
     bf16x8 f0[kGrp][4], f1[kGrp][4];
@@ -671,18 +775,24 @@ constexpr long kSmallBatch = 2048;
 int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* hid, hipStream_t s,
                        bool fuse_head, float* probs, int32_t* labels, bool* fused) {
     if (fused) *fused = false;
+    const bool f8 = m->dtype == MDC_FP8 && m->fp8_e4m3_features;      // the feature matrix holds E4M3 bytes (feat8_index order)
     if (n <= kCoopBatch) {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
-        hipLaunchKernelGGL(vt_dense1_bf16_coop_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(256), kCoopLds, s,
-                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
-                           static_cast<const float*>(m->d_pack[4]), hid);
+#define MDC_LAUNCH_COOP(F) do { \
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_coop_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds)); \
+        hipLaunchKernelGGL(vt_dense1_bf16_coop_kernel<F>, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(256), kCoopLds, s, \
+                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]), \
+                           static_cast<const float*>(m->d_pack[4]), hid); } while (0)
+        if (f8) MDC_LAUNCH_COOP(true); else MDC_LAUNCH_COOP(false);
+#undef MDC_LAUNCH_COOP
         MDC_HIP(hipGetLastError());
         return MDC_OK;
     }
     if (n <= kSmallBatch) {
-        hipLaunchKernelGGL(vt_dense1_bf16_small_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s,
-                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]),
-                           static_cast<const float*>(m->d_pack[4]), hid);
+#define MDC_LAUNCH_SMALL(F) hipLaunchKernelGGL(vt_dense1_bf16_small_kernel<F>, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s, \
+                           static_cast<const unsigned short*>(feat), (long)n, static_cast<const unsigned short*>(m->d_pack[3]), \
+                           static_cast<const float*>(m->d_pack[4]), hid)
+        if (f8) MDC_LAUNCH_SMALL(true); else MDC_LAUNCH_SMALL(false);
+#undef MDC_LAUNCH_SMALL
         MDC_HIP(hipGetLastError());
         return MDC_OK;
     }
@@ -710,7 +820,7 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
     }
 #endif
 #ifdef MDC_ALTERNATES
-    if (m->alt & kAltDense1Simple) {      // one barrier per K-tile (bit-identical results; the phased kernel's race screen)
+    if (!f8 && (m->alt & kAltDense1Simple)) {      // one barrier per K-tile (bit-identical results; the phased kernel's race screen)
         MDC_LAUNCH_D1(0);
         MDC_HIP(hipGetLastError());
         return MDC_OK;
@@ -719,7 +829,7 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
 #endif
 #undef MDC_LAUNCH_D1
 #ifdef MDC_ALTERNATES
-    if (m->alt & kAltDense1Wreg) {      // weight fragments straight from L2 into registers (bit-identical, slower; see the kernel)
+    if (!f8 && (m->alt & kAltDense1Wreg)) {      // weight fragments straight from L2 into registers (bit-identical, slower; see the kernel)
         if (fuse_head && (probs || labels)) {
             MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_wreg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseHeadLds));
             hipLaunchKernelGGL((vt_dense1_bf16_wreg_kernel<true>), grid, dim3(512), kDenseHeadLds, s, f, (long)n, w1t, c1, hid,
@@ -733,15 +843,18 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
         return MDC_OK;
     }
 #endif
-    if (fuse_head && (probs || labels)) {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseHeadLds));
-        hipLaunchKernelGGL((vt_dense1_bf16_phased_kernel<0, true>), grid, dim3(512), kDenseHeadLds, s, f, (long)n, w1t, c1, hid,
-                           static_cast<const float*>(m->d_pack[5]), (int)m->topo.classes, probs, labels);
-        if (fused) *fused = true;
-    } else {
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
-        hipLaunchKernelGGL((vt_dense1_bf16_phased_kernel<0, false>), grid, dim3(512), kDenseBf16Lds, s, f, (long)n, w1t, c1, hid);
-    }
+#define MDC_LAUNCH_PHASED(F) do { \
+    if (fuse_head && (probs || labels)) { \
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseHeadLds)); \
+        hipLaunchKernelGGL((vt_dense1_bf16_phased_kernel<0, true, F>), grid, dim3(512), kDenseHeadLds, s, f, (long)n, w1t, c1, hid, \
+                           static_cast<const float*>(m->d_pack[5]), (int)m->topo.classes, probs, labels); \
+        if (fused) *fused = true; \
+    } else { \
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds)); \
+        hipLaunchKernelGGL((vt_dense1_bf16_phased_kernel<0, false, F>), grid, dim3(512), kDenseBf16Lds, s, f, (long)n, w1t, c1, hid); \
+    } } while (0)
+    if (f8) MDC_LAUNCH_PHASED(true); else MDC_LAUNCH_PHASED(false);
+#undef MDC_LAUNCH_PHASED
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

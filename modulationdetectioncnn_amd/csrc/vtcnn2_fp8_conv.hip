@@ -1,6 +1,9 @@
 // Canonical VT-CNN2 (T3), fp8 mode (MDC_FP8): conv1+conv2 with conv2 on the block-scaled fp8 MFMA
-// (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3, scales 2^0), twice the bf16 MFMA rate; f32 accumulation; the
-// features leave as bf16 exactly as in the bf16 mode, so dense1 and the head are the bf16 mode's kernels.
+// (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3, scales 2^0), twice the bf16 MFMA rate; f32 accumulation.
+// Round 4: the features leave as E4M3 bytes with one power-of-two scale per tensor (F8OUT, the default) -- 10,560 B per
+// frame instead of 21,120 written here and read back by dense1, which converts them to bf16 on the way into its MFMA
+// (exact) and keeps bf16 weights; see "FEATURES" below.  With MDC_OPT_FP8_BF16_FEATURES the features leave as bf16
+// exactly as in the bf16 mode (rounds 1-3), and dense1 and the head are the bf16 mode's kernels.
 //
 // Same structure as vtcnn2_bf16_sched.hip (weight-stationary in registers, wave q = input channels [64q, 64q+64), the
 // K-quarter partials of one output position exchanged per step, asm-sequenced step, helpers of
@@ -29,6 +32,18 @@
 //     dense1's weights 2^+kFeatShift, the finish uses the clamp form.  sa is chosen from the largest |sample| the caller
 //     expects (mdc_set_fp8_input_absmax, default 0.02 = the reference's frames); a larger input
 //     saturates -- "fp8 (scaled inputs)" in the survey's words.
+//   * FEATURES (F8OUT): the finish's last partial-sum add carries the VOP3 clamp bit (the sums are the true values times
+//     2^-kFeatShift, far below 1: clamp to [0, 1] IS the ReLU, as in v_cvt_pk_bf16_f32 ... clamp of the bf16 finish), then
+//     two v_cvt_scalef32_pk_fp8_f32 (divide by st.fsc = 2^-(kFeatShift + kf), round to e4m3, saturate under
+//     MODE.FP16_OVFL; tools/microbench/cvt_bf16_fp8_probe.hip) put a position's four channels into ONE dword: the same
+//     VALU count as the bf16 finish.  kf = floor(log2(224 / bound)) with bound the largest conv2 output the weights allow
+//     for inputs inside the stated range (sum |w2| x conv1 bound + |b2|): never overflows, and sits 4-6 binades below
+//     the best data-fitted scale, where the label agreement is flat (profiles/r03_exp_fp8_features.json: k_best .. -6).
+//     Layout (feat8_index): output positions in groups of FOUR, 320 B each -- per position pair 128 B = sixteen 8-byte
+//     slots {even position's 4 channels, odd position's 4 channels} (one dwordx2 store per pair and lane, none on even
+//     steps), then 64 B = channels 64..79 as (w0, w1, w2, w3) bytes (one dword store per four positions).  The
+//     position-range form (small batches) splits a group between two work-groups, so it stores that dword's halves as
+//     16-bit stores at every odd position.
 // Parity: unpinned like every T3 result (no weights bundled); checked against the f64 oracle at 6e-2 of max|logit|.
 #include "vtcnn2_bf16_common.h"
 #include "vtcnn2_sched_common.h"
@@ -58,6 +73,9 @@ struct Fp8State {
     f32x4 rp[4];
     float rc[4];
     float tprev;              // fifth-tile value of the last even output position (vtcnn2_sched_common.h, sch_fin_clamp)
+    unsigned oe;              // F8OUT: the even position's four e4m3 channels, waiting for the odd position's store
+    unsigned tt;              // F8OUT: channel 64 + 4q + gs of the four positions of a group, one byte each
+    float fsc;                // F8OUT: 2^-(kFeatShift + kf), divisor of v_cvt_scalef32_pk_fp8_f32
     u32x4 L0[3];
     u32x4 L1;
     unsigned cb[4];
@@ -100,10 +118,58 @@ __device__ __forceinline__ void f8_cvt(Fp8State& st) {
     else asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(st.Bf[SP][d]) : "v"(st.T[K]), "v"(st.sc9));
 }
 
+// F8OUT finish of one output position, one VALU per call (K = 0..17; W4 = position & 3): the sum of the four K-quarter
+// partials with the ReLU in the last add's clamp bit, then e4m3 bytes.  An even position leaves its dword in st.oe and its
+// fifth-tile value in st.tprev; the odd one packs its own into out.o0 and the pair's fifth-tile bytes into a half of st.tt.
+template <int K, int W4, class S>
+__device__ __forceinline__ void f8_fin(S& st, FinTmp& f, FinOut& out) {
+    constexpr int ODD = W4 & 1;
+    if constexpr (K < 4) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.s[K]) : "v"(st.rp[0][K]), "v"(st.rp[1][K]));
+    else if constexpr (K < 8) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.u[K - 4]) : "v"(st.rp[2][K - 4]), "v"(st.rp[3][K - 4]));
+    else if constexpr (K < 12) asm volatile("v_add_f32 %0, %0, %1 clamp" : "+v"(f.s[K - 8]) : "v"(f.u[K - 8]));
+    else if constexpr (K == 12) {
+        // ("=v": the first write of the dword; the instruction keeps the other half, which K == 13 then fills)
+        if constexpr (ODD) asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(out.o0) : "v"(f.s[0]), "v"(f.s[1]), "v"(st.fsc));
+        else asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(st.oe) : "v"(f.s[0]), "v"(f.s[1]), "v"(st.fsc));
+    } else if constexpr (K == 13) {
+        if constexpr (ODD) asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(out.o0) : "v"(f.s[2]), "v"(f.s[3]), "v"(st.fsc));
+        else asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(st.oe) : "v"(f.s[2]), "v"(f.s[3]), "v"(st.fsc));
+    } else if constexpr (K == 14) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.a) : "v"(st.rc[0]), "v"(st.rc[1]));
+    else if constexpr (K == 15) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f.b) : "v"(st.rc[2]), "v"(st.rc[3]));
+    else if constexpr (K == 16) {
+        if constexpr (ODD) asm volatile("v_add_f32 %0, %1, %2 clamp" : "=v"(f.t) : "v"(f.a), "v"(f.b));
+        else asm volatile("v_add_f32 %0, %1, %2 clamp" : "=v"(st.tprev) : "v"(f.a), "v"(f.b));
+    } else if constexpr (ODD) {
+        if constexpr (W4 == 1) asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(st.tt) : "v"(st.tprev), "v"(f.t), "v"(st.fsc));
+        else asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(st.tt) : "v"(st.tprev), "v"(f.t), "v"(st.fsc));
+    }
+}
+template <int W4, class S>
+__device__ __forceinline__ void f8_fin_all(S& st, FinOut& out) {
+    FinTmp f;
+    [&]<int... K>(std::integer_sequence<int, K...>) { (f8_fin<K, W4>(st, f, out), ...); }(std::make_integer_sequence<int, 18>{});
+}
+// F8OUT stores of the finishing lane (frame row frow, bytes; feat8_index layout).  WHICH = 0, after an ODD position w:
+// channels [16q+4gs, +4) of positions w-1 and w as one dwordx2.  WHICH = 1: channel 64+4q+gs -- batch form: the group's
+// dword after its last position (W4 == 3); range form: the pair's two bytes after every odd position.
+template <int WHICH, int W4, bool RANGE, class S>
+__device__ __forceinline__ void f8_store(const S& st, const FinOut& fo, unsigned char* frow, int w, int q, int gs) {
+    unsigned char* grp = frow + (long)(w >> 2) * (4 * kC2);
+    if constexpr (WHICH == 0) {
+        if constexpr ((W4 & 1) == 1) *reinterpret_cast<u32x2*>(grp + (W4 >> 1) * 128 + 8 * (4 * q + gs)) = u32x2{st.oe, fo.o0};
+    } else if constexpr (RANGE) {
+        if constexpr (W4 == 1) *reinterpret_cast<unsigned short*>(grp + 256 + 4 * (4 * q + gs)) = (unsigned short)(st.tt & 0xFFFFu);
+        else if constexpr (W4 == 3) *reinterpret_cast<unsigned short*>(grp + 256 + 4 * (4 * q + gs) + 2) = (unsigned short)(st.tt >> 16);
+    } else {
+        if constexpr (W4 == 3) *reinterpret_cast<unsigned*>(grp + 256 + 4 * (4 * q + gs)) = st.tt;
+    }
+}
+
 // One position step: 15 conv2 MFMAs + 2 conv1 MFMAs, every gap 32 cycles (2 VALU, or 1 VALU + 1 LDS, ride for free).
 // RANGE / wlo: the position-range form for small batches (vtcnn2_bf16_sched.hip): outputs below wlo are not stored
-template <int V12, bool FIRST, bool LAST, bool RANGE = false>
-__device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned short* fbase, f32x4 (&acc)[3][5], int wlo = 0) {
+template <int V12, bool FIRST, bool LAST, bool RANGE = false, bool F8OUT = true>
+__device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, typename std::conditional<F8OUT, unsigned char, unsigned short>::type* fbase,
+                                        f32x4 (&acc)[3][5], int wlo = 0) {
     constexpr int PAR = V12 & 1, PN = 1 - PAR;
     constexpr int R1 = (V12 + 1) & 3, S0 = ((V12 + 1) >> 2) % 3, SN = (S0 + 1) % 3;
     constexpr bool kLoadEven = (V12 & 3) == 1 && !LAST, kLoadOdd = (V12 & 3) == 3 && !LAST;
@@ -115,10 +181,12 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
     FinTmp ft;
     FinOut fo;
     constexpr int OP = (V12 + 1) & 1;      // parity of the output position v - 1 this step finishes
-#define FIN(K) do { if (!FIRST) sch_fin_clamp<K, OP>(st, ft, fo); } while (0)
+    constexpr int W4 = (V12 + 3) & 3;      // ... and its place in its group of four (v = V12 mod 12 in every call)
+#define FIN(K) do { if (!FIRST) { if constexpr (F8OUT) f8_fin<K, W4>(st, ft, fo); else sch_fin_clamp<K, OP>(st, ft, fo); } } while (0)
 #define PREP(I) do { if (!LAST) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
-#define ST(W) do { if (!FIRST && (W == 0 || OP == 1)) { if (!RANGE || v - 1 >= wlo) sch_store<W>(fo, fbase, v - 1, q, st.gs); } } while (0)
+#define ST(W) do { if (!FIRST && (W == 0 || OP == 1)) { if (!RANGE || v - 1 >= wlo) { \
+        if constexpr (F8OUT) f8_store<W, W4, RANGE>(st, fo, fbase, v - 1, q, st.gs); else sch_store<W>(fo, fbase, v - 1, q, st.gs); } } } while (0)
 #define WR(OT) sch_part_write<PAR, OT>(st, a2[OT])
 #define PKB(K) do { if (!LAST) f8_pkb<K>(st); } while (0)
 #define CV(K) do { if (!LAST) f8_cvt<PN, K>(st); } while (0)
@@ -169,11 +237,13 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, unsigned sho
 
 // RANGE: grid (groups, 11), work-group (g, r) runs steps 12r .. 12r+13 (r = 10: 120 .. 129 and the tail) and stores the
 // outputs 12r+2 .. 12r+13 (r = 0: from 0; r = 10: 122 .. 131) -- see vt_conv_bf16_sched_kernel
-template <bool U8, bool RANGE = false>
+template <bool U8, bool RANGE = false, bool F8OUT = true>
 __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __restrict__ x, long n,
                                                              const u32x8* __restrict__ wq, const u32x4* __restrict__ a1q,
-                                                             const float* __restrict__ b2, unsigned short* __restrict__ feat,
-                                                             long hop2, float scale, unsigned scale_b_e8m0) {
+                                                             const float* __restrict__ b2, void* __restrict__ feat_out,
+                                                             long hop2, float scale, unsigned scale_b_e8m0, float feat_divisor) {
+    using FeatT = typename std::conditional<F8OUT, unsigned char, unsigned short>::type;      // e4m3 bytes / bf16
+    FeatT* __restrict__ feat = static_cast<FeatT*>(feat_out);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* img = reinterpret_cast<unsigned*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -194,7 +264,9 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     st.one = 0x7F7F7F7Fu;
     st.scb = scale_b_e8m0 * 0x01010101u;
     st.sc9 = 0.001953125f;
-    asm volatile("" : "+v"(st.one), "+v"(st.scb), "+v"(st.sc9));
+    st.fsc = feat_divisor;
+    st.oe = st.tt = 0u;
+    asm volatile("" : "+v"(st.one), "+v"(st.scb), "+v"(st.sc9), "+v"(st.fsc), "+v"(st.oe), "+v"(st.tt));
 #pragma unroll
     for (int k = 0; k < 16; ++k) st.T[k] = 0u;
 #pragma unroll
@@ -235,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
     int buf = 0;
     for (; grp < ngroups; grp += gridDim.x, buf ^= 1) {
         st.im_addr = img_lds + (buf * kSImgWords + lane * kS) * 4;
-        unsigned short* fbase = feat + (grp * 16 + fs) * (long)(kW2 * kC2);
+        FeatT* fbase = feat + (grp * 16 + fs) * (long)(kW2 * kC2);
         const long gnext = RANGE ? ngroups : grp + gridDim.x;
         // accumulators of outputs 0 and 1 start from the bias: an MFMA (0 x 0 + bias), never a compiler AGPR copy
         f32x4 acc[3][5];
@@ -257,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
         [&]<int... K>(std::integer_sequence<int, K...>) { (f8_cvt<0, K>(st), ...); }(std::make_integer_sequence<int, 16>{});
         asm volatile("s_nop 1");
 
-        f8_step<0, true, false, RANGE>(st, S, q, fbase, acc, wlo);
+        f8_step<0, true, false, RANGE, F8OUT>(st, S, q, fbase, acc, wlo);
         // batch form: 10 x 12 steps (v = 1 .. 120), then 121 .. 129; range form: one pass of the 12-step body and step
         // S+13 for the ranges 0 .. 9, none for the last one
         const int iters = RANGE ? (rng < 10 ? 1 : 0) : 10;
@@ -268,52 +340,66 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
                 if (it >= 6 && gnext < ngroups) sch_stage_write(it - 6, stage_decode<U8>(sv, tid, scale), n, gnext * 16, img + (buf ^ 1) * kSImgWords, tid);
                 if (it >= 5 && it < 9 && gnext < ngroups) sv = stage_load<U8>(it - 5, x, n, gnext * 16, tid, hop2);
             }
-            f8_step<1, false, false, RANGE>(st, v + 0, q, fbase, acc, wlo);
-            f8_step<2, false, false, RANGE>(st, v + 1, q, fbase, acc, wlo);
-            f8_step<3, false, false, RANGE>(st, v + 2, q, fbase, acc, wlo);
-            f8_step<4, false, false, RANGE>(st, v + 3, q, fbase, acc, wlo);
-            f8_step<5, false, false, RANGE>(st, v + 4, q, fbase, acc, wlo);
-            f8_step<6, false, false, RANGE>(st, v + 5, q, fbase, acc, wlo);
-            f8_step<7, false, false, RANGE>(st, v + 6, q, fbase, acc, wlo);
-            f8_step<8, false, false, RANGE>(st, v + 7, q, fbase, acc, wlo);
-            f8_step<9, false, false, RANGE>(st, v + 8, q, fbase, acc, wlo);
-            f8_step<10, false, false, RANGE>(st, v + 9, q, fbase, acc, wlo);
-            f8_step<11, false, false, RANGE>(st, v + 10, q, fbase, acc, wlo);
-            f8_step<0, false, false, RANGE>(st, v + 11, q, fbase, acc, wlo);
+            f8_step<1, false, false, RANGE, F8OUT>(st, v + 0, q, fbase, acc, wlo);
+            f8_step<2, false, false, RANGE, F8OUT>(st, v + 1, q, fbase, acc, wlo);
+            f8_step<3, false, false, RANGE, F8OUT>(st, v + 2, q, fbase, acc, wlo);
+            f8_step<4, false, false, RANGE, F8OUT>(st, v + 3, q, fbase, acc, wlo);
+            f8_step<5, false, false, RANGE, F8OUT>(st, v + 4, q, fbase, acc, wlo);
+            f8_step<6, false, false, RANGE, F8OUT>(st, v + 5, q, fbase, acc, wlo);
+            f8_step<7, false, false, RANGE, F8OUT>(st, v + 6, q, fbase, acc, wlo);
+            f8_step<8, false, false, RANGE, F8OUT>(st, v + 7, q, fbase, acc, wlo);
+            f8_step<9, false, false, RANGE, F8OUT>(st, v + 8, q, fbase, acc, wlo);
+            f8_step<10, false, false, RANGE, F8OUT>(st, v + 9, q, fbase, acc, wlo);
+            f8_step<11, false, false, RANGE, F8OUT>(st, v + 10, q, fbase, acc, wlo);
+            f8_step<0, false, false, RANGE, F8OUT>(st, v + 11, q, fbase, acc, wlo);
         }
         const int vt = RANGE ? v : 121;
-        f8_step<1, false, false, RANGE>(st, vt, q, fbase, acc, wlo);
+        f8_step<1, false, false, RANGE, F8OUT>(st, vt, q, fbase, acc, wlo);
         if constexpr (RANGE) {
             if (rng < 10) {      // finish of output S+13; the accumulators of S+14, S+15 are dropped
                 FinOut fo;
                 sch_wait_lds(st);
-                sch_fin_all_clamp<1>(st, fo);      // S + 13 is odd: the pair (S + 12, S + 13)
-                sch_store<0>(fo, fbase, vt, q, st.gs);
-                sch_store<1>(fo, fbase, vt, q, st.gs);
+                if constexpr (F8OUT) {              // S + 13 is odd and second in its group of four: the pair (S + 12, S + 13)
+                    f8_fin_all<1>(st, fo);
+                    f8_store<0, 1, true>(st, fo, fbase, vt, q, st.gs);
+                    f8_store<1, 1, true>(st, fo, fbase, vt, q, st.gs);
+                } else {
+                    sch_fin_all_clamp<1>(st, fo);
+                    sch_store<0>(fo, fbase, vt, q, st.gs);
+                    sch_store<1>(fo, fbase, vt, q, st.gs);
+                }
                 asm volatile("s_nop 7\n\ts_nop 7" ::"a"(acc[0][0]), "a"(acc[1][0]), "a"(acc[2][0]));
                 __syncthreads();
                 continue;
             }
         }
-        f8_step<2, false, false, RANGE>(st, 122, q, fbase, acc, wlo);
-        f8_step<3, false, false, RANGE>(st, 123, q, fbase, acc, wlo);
-        f8_step<4, false, false, RANGE>(st, 124, q, fbase, acc, wlo);
-        f8_step<5, false, false, RANGE>(st, 125, q, fbase, acc, wlo);
-        f8_step<6, false, false, RANGE>(st, 126, q, fbase, acc, wlo);
-        f8_step<7, false, false, RANGE>(st, 127, q, fbase, acc, wlo);
-        f8_step<8, false, false, RANGE>(st, 128, q, fbase, acc, wlo);
-        f8_step<9, false, true, RANGE>(st, 129, q, fbase, acc, wlo);
+        f8_step<2, false, false, RANGE, F8OUT>(st, 122, q, fbase, acc, wlo);
+        f8_step<3, false, false, RANGE, F8OUT>(st, 123, q, fbase, acc, wlo);
+        f8_step<4, false, false, RANGE, F8OUT>(st, 124, q, fbase, acc, wlo);
+        f8_step<5, false, false, RANGE, F8OUT>(st, 125, q, fbase, acc, wlo);
+        f8_step<6, false, false, RANGE, F8OUT>(st, 126, q, fbase, acc, wlo);
+        f8_step<7, false, false, RANGE, F8OUT>(st, 127, q, fbase, acc, wlo);
+        f8_step<8, false, false, RANGE, F8OUT>(st, 128, q, fbase, acc, wlo);
+        f8_step<9, false, true, RANGE, F8OUT>(st, 129, q, fbase, acc, wlo);
         // tail: finish 129, then outputs 130 and 131 (complete as they are: only zero padding beyond).
         // step 129 (v%3 == 0) left output 130 in acc[1] and output 131 in acc[2].
-        auto finish_store = [&](auto odd, int w) {
+        auto finish_store = [&](auto w4, int w) {      // w4 = w & 3 (129, 130, 131 -> 1, 2, 3)
+            constexpr int W4 = decltype(w4)::value;
             FinOut fo;
             sch_wait_lds(st);
-            sch_fin_all_clamp<decltype(odd)::value>(st, fo);
-            sch_store<0>(fo, fbase, w, q, st.gs);
-            if constexpr (decltype(odd)::value) sch_store<1>(fo, fbase, w, q, st.gs);
+            if constexpr (F8OUT) {
+                f8_fin_all<W4>(st, fo);
+                f8_store<0, W4, RANGE>(st, fo, fbase, w, q, st.gs);
+                f8_store<1, W4, RANGE>(st, fo, fbase, w, q, st.gs);
+            } else {
+                sch_fin_all_clamp<W4 & 1>(st, fo);
+                sch_store<0>(fo, fbase, w, q, st.gs);
+                if constexpr (W4 & 1) sch_store<1>(fo, fbase, w, q, st.gs);
+            }
         };
-        using Even = std::integral_constant<int, 0>;
+        using Even = std::integral_constant<int, 2>;
         using Odd = std::integral_constant<int, 1>;
+        using Last = std::integral_constant<int, 3>;
         finish_store(Odd{}, 129);
         asm volatile("s_nop 7\n\ts_nop 7");       // last tap-1/tap-0 MFMAs -> ds_write of their accumulators
         sch_part_write<0, 0>(st, acc[1][0]); sch_part_write<0, 1>(st, acc[1][1]); sch_part_write<0, 2>(st, acc[1][2]);
@@ -327,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void vt_conv_fp8_kernel(const float* __rest
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         sch_red_load<1>(st);
         asm volatile("" ::"a"(acc[2][0]), "a"(acc[2][1]), "a"(acc[2][2]), "a"(acc[2][3]), "a"(acc[2][4]));
-        finish_store(Odd{}, 131);
+        finish_store(Last{}, 131);
         __syncthreads();      // next group's image is complete; partial buffers are free again
     }
 }
@@ -410,14 +496,37 @@ int vtcnn2_fp8_pack(mdc_model* m) {
     std::vector<float> b2s(kC2);
     for (int o = 0; o < kC2; ++o) b2s[o] = std::ldexp(m->hb[1][o], -kFeatShift);
     if ((rc = upload(m, 2, b2s.data(), b2s.size() * sizeof(float)))) return rc;
-    // dense1: exactly the bf16 mode's (its features carry the same 2^-kFeatShift)
+    // dense1.  bf16 features (MDC_OPT_FP8_BF16_FEATURES): exactly the bf16 mode's (its features carry the same 2^-kFeatShift).
+    // E4M3 features: true value x 2^kf with kf from the largest conv2 output the weights allow for inputs inside the
+    // stated range -- per output channel sum_c,h,j |w2| x (conv1 bound of channel c) + |b2| -- so that nothing inside the
+    // range saturates (see the header); K in feat8_index order; the weights carry 2^-kf (a power of two: exact in bf16).
+    m->fp8_e4m3_features = (m->topo.reserved[0] & MDC_OPT_FP8_BF16_FEATURES) == 0;
+    int kf = 0;
+    if (m->fp8_e4m3_features) {
+        float bound = 0.f;
+        for (int o = 0; o < kC2; ++o) {
+            double acc = std::fabs((double)m->hb[1][o]);
+            for (int ch = 0; ch < kC1; ++ch) {
+                const double c1b = (double)m->fp8_input_absmax * (std::fabs(k1[ch * 3]) + std::fabs(k1[ch * 3 + 1]) + std::fabs(k1[ch * 3 + 2])) + std::fabs(b1[ch]);
+                double wsum = 0.0;
+                for (int t = 0; t < 6; ++t) wsum += std::fabs((double)k2[((size_t)o * kC1 + ch) * 6 + t]);
+                acc += wsum * c1b;
+            }
+            bound = std::fmax(bound, (float)acc);
+        }
+        if (!(bound > 0.f) || !std::isfinite(bound)) { set_error("fp8: degenerate conv2 output bound"); return MDC_EINVAL; }
+        kf = (int)std::floor(std::log2(224.f / bound));
+        if (kFeatShift + kf < -120 || kFeatShift + kf > 120) { set_error("fp8: feature scale 2^%d out of range", kf); return MDC_EINVAL; }
+        m->feat_scale_log2 = kf;
+        m->fp8_feat_divisor = std::ldexp(1.f, -(kFeatShift + kf));      // sums are true x 2^-kFeatShift; bytes are true x 2^kf
+    }
     const float* w1 = m->hk[2].data();
-    const float inv = std::ldexp(1.f, kFeatShift);
+    const float inv = std::ldexp(1.f, m->fp8_e4m3_features ? -kf : kFeatShift);
     std::vector<unsigned short> w1t((size_t)kHid * kFeat);
     for (int w = 0; w < kW2; ++w)
         for (int o = 0; o < kC2; ++o) {
             const float* srcw = w1 + (size_t)(o * kW2 + w) * kHid;
-            const int kk = feat16_index(w, o);
+            const int kk = m->fp8_e4m3_features ? feat8_index(w, o) : feat16_index(w, o);
             for (int nn = 0; nn < kHid; ++nn) w1t[((size_t)(kk >> 6) * kHid + nn) * 64 + (kk & 63)] = f2bf(srcw[nn] * inv);
         }
     return upload(m, 3, w1t.data(), w1t.size() * 2);
@@ -426,20 +535,22 @@ int vtcnn2_fp8_pack(mdc_model* m) {
 int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, hipStream_t s, long hop2, float scale) {
     const long ngroups = (n + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
-#define MDC_LAUNCH_F8(U, R, GRID) do { \
-    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<U, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
-    hipLaunchKernelGGL((vt_conv_fp8_kernel<U, R>), GRID, dim3(256), kSchedLds, s, x, (long)n, \
+#define MDC_LAUNCH_F8(U, R, F, GRID) do { \
+    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_conv_fp8_kernel<U, R, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchedLds)); \
+    hipLaunchKernelGGL((vt_conv_fp8_kernel<U, R, F>), GRID, dim3(256), kSchedLds, s, x, (long)n, \
                        static_cast<const u32x8*>(m->d_pack[0]), static_cast<const u32x4*>(m->d_pack[1]), \
-                       static_cast<const float*>(m->d_pack[2]), static_cast<unsigned short*>(feat), hop2 > 0 ? hop2 : 256L, scale, \
-                       (unsigned)m->fp8_feat_scale_log2); } while (0)
+                       static_cast<const float*>(m->d_pack[2]), feat, hop2 > 0 ? hop2 : 256L, scale, \
+                       (unsigned)m->fp8_feat_scale_log2, m->fp8_feat_divisor); } while (0)
+#define MDC_LAUNCH_F8_UR(U, R, GRID) do { if (m->fp8_e4m3_features) MDC_LAUNCH_F8(U, R, true, GRID); else MDC_LAUNCH_F8(U, R, false, GRID); } while (0)
     // hop2 > 0: raw uint8 I/Q straight into the staging.  Small batches: the position-range form (results identical)
     if (n <= kConvRangeFrames) {
-        if (hop2 > 0) MDC_LAUNCH_F8(true, true, dim3((unsigned)ngroups, 11));
-        else MDC_LAUNCH_F8(false, true, dim3((unsigned)ngroups, 11));
+        if (hop2 > 0) MDC_LAUNCH_F8_UR(true, true, dim3((unsigned)ngroups, 11));
+        else MDC_LAUNCH_F8_UR(false, true, dim3((unsigned)ngroups, 11));
     } else {
-        if (hop2 > 0) MDC_LAUNCH_F8(true, false, dim3(grid));
-        else MDC_LAUNCH_F8(false, false, dim3(grid));
+        if (hop2 > 0) MDC_LAUNCH_F8_UR(true, false, dim3(grid));
+        else MDC_LAUNCH_F8_UR(false, false, dim3(grid));
     }
+#undef MDC_LAUNCH_F8_UR
 #undef MDC_LAUNCH_F8
     MDC_HIP(hipGetLastError());
     return MDC_OK;

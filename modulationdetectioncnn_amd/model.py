@@ -50,13 +50,18 @@ class VTCNN2:
     MAX_WORKSPACES = 4
 
     def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
-                 fp8_input_absmax: Optional[float] = None, _lib_variant: str = "product"):
+                 fp8_input_absmax: Optional[float] = None, fp8_bf16_features: bool = False, _lib_variant: str = "product"):
         """dtype "f32" | "bf16" (vtcnn2, deployed) | "f16" (deployed) | "fp8" (vtcnn2, deployed).  fp8_input_absmax: the largest
         |I/Q sample| the fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs saturate.
+        fp8_bf16_features (vtcnn2 at "fp8" only): MDC_OPT_FP8_BF16_FEATURES -- keep the conv2 features in bf16 as before
+        ABI 4 instead of E4M3 bytes (twice the feature traffic, the old numerics).
         _lib_variant: tests only (the alternates build)."""
         self.topology = topology
         self.dtype = dtype
         self.fp8_input_absmax = fp8_input_absmax
+        self.fp8_bf16_features = bool(fp8_bf16_features)
+        if self.fp8_bf16_features and not (topology.kind == "vtcnn2" and dtype == "fp8"):
+            raise ValueError("fp8_bf16_features is an option of the vtcnn2 family's fp8 mode")
         self._lib_variant = _lib_variant
         if dtype not in _DTYPE:
             raise ValueError(f"dtype must be one of {sorted(_DTYPE)}")
@@ -210,7 +215,8 @@ class VTCNN2:
             raise RuntimeError("no ROCm device visible: the MI355X path has no CPU fallback")
         L = self._lib()
         t = self.topology
-        topo = _cabi.MdcTopology(_KIND[t.kind], t.filters, t.hidden, t.classes, (C.c_int32 * 4)(0, 0, 0, 0))
+        topo = _cabi.MdcTopology(_KIND[t.kind], t.filters, t.hidden, t.classes,
+                                 (C.c_int32 * 4)(_cabi.MDC_OPT_FP8_BF16_FEATURES if self.fp8_bf16_features else 0, 0, 0, 0))
         h = C.c_void_p()
         self._check(L.mdc_create(C.byref(topo), self.device_index, C.byref(h)))
         try:

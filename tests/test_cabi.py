@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         L = ctypes.CDLL(lib)
         for name in _declared():
             assert hasattr(L, name), (variant, name)
-        assert L.mdc_abi_version() == _cabi.ABI_VERSION == 3
+        assert L.mdc_abi_version() == _cabi.ABI_VERSION == 4
 
 
 def test_product_library_has_one_kernel_per_role_and_never_reads_the_environment():
@@ -93,7 +93,7 @@ def test_header_is_plain_c99(tmp_path):
     """include/mdc.h compiles as C99 with -Wall -Werror -pedantic and nothing but the standard headers."""
     import subprocess
     src = tmp_path / "hdr.c"
-    src.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 3 && MDC_HOP_FRAME == 128 && MDC_OPT_ALL == 0 ? 0 : 1; }\n')
+    src.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 4 && MDC_HOP_FRAME == 128 && MDC_OPT_ALL == 1 && MDC_OPT_FP8_BF16_FEATURES == 1 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "hdr")], check=True)
     assert subprocess.run([str(tmp_path / "hdr")]).returncode == 0
 

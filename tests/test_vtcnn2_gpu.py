@@ -7,15 +7,18 @@ homogeneous in its input scale):
   f32 path : 2e-5   (exact-f32 MFMA fma chains, K up to 10560)
   bf16 path: 8e-3   (bf16 operands, f32 accumulation; the largest error over this file's scenarios is 3.8e-3 on the logits,
                      4.0e-3 on the features, 8e-4 on the probabilities: tools/measure_bars.py -> profiles/r03_measured_bars.json)
-  fp8 path : 5e-2   (conv2 on e4m3 operands, measured 4.0e-2 / 3.7e-2 / 1.2e-2; activations scaled for a stated input range)
+  fp8 path : 5e-2   (conv2 on e4m3 operands, measured 4.0e-2 / 3.7e-2 / 1.2e-2; activations scaled for a stated input range;
+                     round 4: E4M3 features between conv2 and dense1 as well -- the 'flat' / 'conv' taps carry that rounding, v/16)
 i.e. about twice (fp8: 1.25 x) what is measured -- round 2's 2e-2 / 8e-2 would have passed a kernel three times as wrong.
 Probabilities: half the logit bar (softmax contracts).  Labels: bit-exact wherever the oracle's top-2 logit margin
 exceeds 4x the tolerance; every frame counts in tests/test_label_agreement_gpu.py."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
 
-from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames, synthetic_weights
+from modulationdetectioncnn_amd import VTCNN2, Topology, _cabi, synthetic_frames, synthetic_weights
 from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
@@ -81,7 +84,10 @@ def test_taps(dtype):
     tol = TOL[dtype]
     flat = m.predict(x, tap="flat")
     assert flat.shape == (40, 10560)
-    assert np.abs(flat - ref["flat"]).max() <= tol * np.abs(ref["flat"]).max()
+    # fp8 mode (round 4): the features themselves are E4M3 values (x a power of two) -- a value v in [2^e, 2^(e+1)) sits
+    # within 2^(e-4) <= v/16 of its byte, on top of the conv's own error
+    flat_tol = tol + (1.0 / 16 if dtype == "fp8" else 0.0)
+    assert np.abs(flat - ref["flat"]).max() <= flat_tol * np.abs(ref["flat"]).max()
     conv = m.predict(x, tap="conv")
     assert conv.shape == (40, 80, 132)
     np.testing.assert_array_equal(conv.reshape(40, -1), flat)
@@ -116,6 +122,49 @@ def test_f32_larger_batch_statistics():
     x = synthetic_frames(1500, seed=99)
     _, frac = _check(m, w, x, "f32")
     assert frac > 0.999
+
+
+def test_fp8_feature_formats():
+    """MDC_FP8 keeps its conv2 features as E4M3 bytes (the default since ABI 4: 11,584 workspace bytes per frame) or, with
+    MDC_OPT_FP8_BF16_FEATURES, as bf16 (22,144: rounds 1-3).  Every value of the E4M3 'flat' tap is an E4M3 number times
+    ONE power of two; both formats meet the mode's logit bar against the f64 oracle, and the bf16 one is closer on the
+    features (8 significant bits instead of 4); the option is refused outside the fp8 mode."""
+    x = synthetic_frames(512, seed=21)
+    topo = Topology.vtcnn2(11)
+    w = synthetic_weights(topo, seed=2016)
+    ref = O.forward("vtcnn2", x, w, dtype=np.float64)
+    scale = np.abs(ref["logits"]).max()
+    errs = {}
+    for bf in (False, True):
+        m = VTCNN2(topo, dtype="fp8", fp8_bf16_features=bf)
+        m.set_weights(w)
+        lg = m.predict(x, tap="dense")
+        errs[bf] = float(np.abs(lg - ref["logits"]).max() / scale)
+        assert errs[bf] <= TOL["fp8"], (bf, errs[bf])
+        per_frame = _cabi.lib().mdc_workspace_bytes(m._engine(), 1 << 16) / (1 << 16)
+        assert per_frame == (22144 if bf else 11584)
+        flat = m.predict(x[:64], tap="flat").astype(np.float64)
+        nz = flat[flat > 0]
+        # mantissa of every feature in the E4M3 grid: v = m * 2^e with m in {8..15}/8 (normals) -- i.e. v / 2^floor(log2 v) * 8 is an integer
+        frac = nz / 2.0 ** np.floor(np.log2(nz)) * 8
+        on_grid = np.abs(frac - np.round(frac)) < 1e-9
+        assert on_grid.all() == (not bf), (bf, on_grid.mean())      # (e4m3 subnormals are on that grid too; bf16 features are not)
+        ferr = float(np.abs(flat - ref["flat"][:64]).max() / np.abs(ref["flat"][:64]).max())
+        errs[("flat", bf)] = ferr
+    assert errs[("flat", True)] < errs[("flat", False)] <= TOL["fp8"] + 1 / 16
+    with pytest.raises(ValueError):
+        VTCNN2(topo, dtype="bf16", fp8_bf16_features=True)
+    t = _cabi.MdcTopology(2, 256, 256, 11, (ctypes.c_int32 * 4)(_cabi.MDC_OPT_FP8_BF16_FEATURES, 0, 0, 0))
+    h = ctypes.c_void_p()
+    L = _cabi.lib()
+    assert L.mdc_create(ctypes.byref(t), 0, ctypes.byref(h)) == 0
+    try:
+        for i, (k, b) in enumerate(w):
+            assert L.mdc_set_weights(h, i, k.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), k.size, b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.size) == 0
+        L.mdc_last_error.restype = ctypes.c_char_p
+        assert L.mdc_finalize(h, 1) == -22 and b"MDC_FP8" in L.mdc_last_error()      # the option at MDC_BF16
+    finally:
+        L.mdc_destroy(h)
 
 
 def test_fp8_rejects_other_topologies_and_bad_scale():
