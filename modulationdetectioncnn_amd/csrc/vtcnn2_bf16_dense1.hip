@@ -33,15 +33,14 @@ constexpr size_t kDenseHeadLds = (size_t)128 * kChainXld * 4;  // fused head: [1
 static_assert(kDenseHeadLds >= kDenseBf16Lds, "the fused-head form allocates the larger of the two");
 constexpr int kNT = kFeat / kBK;                              // 165 K-tiles
 
-// 8 E4M3 bytes (k ascending) -> the bf16x8 MFMA operand; x 1.0, exact
+// 8 E4M3 bytes (k ascending) -> the bf16x8 MFMA operand; x 1.0, exact.  The builtin (not inline asm) so that hipcc's
+// scheduler sees four VALU instructions it may place between MFMAs (__builtin_amdgcn_sched_group_barrier below).
 __device__ __forceinline__ bf16x8 cvt_e4m3x8(u32x2 r) {
-    u32x4 o;
-    const float one = 1.0f;
-    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2" : "=v"(o[0]) : "v"(r[0]), "v"(one));
-    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(o[1]) : "v"(r[0]), "v"(one));
-    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2" : "=v"(o[2]) : "v"(r[1]), "v"(one));
-    asm("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(o[3]) : "v"(r[1]), "v"(one));
-    return __builtin_bit_cast(bf16x8, o);
+    const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], 1.0f, false);
+    const bf16x2 p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], 1.0f, true);
+    const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], 1.0f, false);
+    const bf16x2 p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], 1.0f, true);
+    return bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
 }
 
 
@@ -356,6 +355,32 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
+    // F8: a quadrant whose 16 MFMAs carry the conversion of eight raw fragments (32 VALU) in their issue shadow -- two
+    // conversions behind every MFMA, pinned with sched_group_barrier (a block of 32 conversions in front of or behind the
+    // MFMAs sits on the wave row's critical path between two barriers: measured, no gain over bf16 features).
+    // OWN: ra -> a, the fragments this very quadrant multiplies (a's first fragment converted up front, fragment f + 1
+    // under the MFMAs of fragment f); otherwise ra -> dst while a x bq is multiplied (the next tile's a0 in phase 3).
+    auto quadrant_cv = [&](bf16x8 (&a)[4][2], const bf16x8 (&bq)[2][2], int i0, int j0, bf16x8 (&dst)[4][2], auto own) {
+        constexpr bool OWN = decltype(own)::value;
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (OWN) a[0][0] = cvt_e4m3x8(ra[0][0]);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int ks = f >> 2, i = f & 3;
+            if constexpr (OWN) { if (f + 1 < 8) a[(f + 1) & 3][(f + 1) >> 2] = cvt_e4m3x8(ra[(f + 1) & 3][(f + 1) >> 2]); }
+            else dst[i][ks] = cvt_e4m3x8(ra[i][ks]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bq[j][ks], acc[i0 + i][j0 + j], 0, 0, 0);
+        }
+        if constexpr (OWN) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU: the first fragment
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                      // two conversions
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
 #define D1_WAIT_BARRIER(N) do { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #define D1_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -402,8 +427,8 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         read_a(a1, 3, b);
         if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier();
         D1_LGKM();
-        cvt_a(a1);
-        quadrant(a1, b1, 4, 2);
+        if constexpr (F8) quadrant_cv(a1, b1, 4, 2, a1, std::true_type{});
+        else quadrant(a1, b1, 4, 2);
         __builtin_amdgcn_s_barrier();
         // phase 3: quadrant (a1, b0); a0 of tile t+1
         if (more) stage_unit(t + 1, 3, b ^ 1);
@@ -411,9 +436,14 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         if (more) read_a(a0, 0, b ^ 1);
         if constexpr (F8) { if (more) D1_WAIT_BARRIER(3); else __builtin_amdgcn_s_barrier(); }
         else { if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier(); }
-        quadrant(a1, b0, 4, 0);
-        D1_LGKM();
-        if (more) cvt_a(a0);
+        if constexpr (F8) {
+            D1_LGKM();      // the next tile's a0 bytes (read before the barrier above) are converted under this quadrant's MFMAs
+            if (more) quadrant_cv(a1, b0, 4, 0, a0, std::false_type{});
+            else quadrant(a1, b0, 4, 0);
+        } else {
+            quadrant(a1, b0, 4, 0);
+            D1_LGKM();
+        }
         __builtin_amdgcn_s_barrier();
     }
 #ifndef D1_NOSTAGGER

@@ -180,17 +180,32 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, typename std
     const unsigned load_addr = st.im_addr + ((v >> 2) * 16 + (kLoadEven ? 16 : 24));
     FinTmp ft;
     FinOut fo;
+#ifdef F8P
+    ft.s[0] = st.rp[0][0]; ft.s[1] = st.rp[0][1]; ft.s[2] = st.rp[0][2]; ft.s[3] = st.rp[0][3]; ft.a = ft.b = ft.t = st.rc[0]; fo.o0 = fo.o1 = fo.tt = 0u;
+#endif
     constexpr int OP = (V12 + 1) & 1;      // parity of the output position v - 1 this step finishes
     constexpr int W4 = (V12 + 3) & 3;      // ... and its place in its group of four (v = V12 mod 12 in every call)
+#ifdef F8P      // timing-only probes (tools/probe_f8_conv.sh; results wrong by construction; never in a shipped library)
+    // 1: no partial-sum adds (the K-quarter chain's upper bound)   2: ... and only the own-quarter partial reads
+    // 3: ... and no ReLU / e4m3 pack of conv1   5: MFMAs, barrier and stores only
+#define FIN(K) do { if (!FIRST && !(K < 12 && F8P >= 1) && !(F8P >= 5)) { if constexpr (F8OUT) f8_fin<K, W4>(st, ft, fo); else sch_fin_clamp<K, OP>(st, ft, fo); } } while (0)
+#else
 #define FIN(K) do { if (!FIRST) { if constexpr (F8OUT) f8_fin<K, W4>(st, ft, fo); else sch_fin_clamp<K, OP>(st, ft, fo); } } while (0)
+#endif
 #define PREP(I) do { if (!LAST) sch_prep<R1, S0, SN, I>(st); } while (0)
 #define C1M(CT) do { if (!LAST) sch_conv1_mfma<R1, S0, CT>(st); } while (0)
 #define ST(W) do { if (!FIRST && (W == 0 || OP == 1)) { if (!RANGE || v - 1 >= wlo) { \
         if constexpr (F8OUT) f8_store<W, W4, RANGE>(st, fo, fbase, v - 1, q, st.gs); else sch_store<W>(fo, fbase, v - 1, q, st.gs); } } } while (0)
 #define WR(OT) sch_part_write<PAR, OT>(st, a2[OT])
+#ifdef F8P
+#define PKB(K) do { if (!LAST && F8P < 3) f8_pkb<K>(st); } while (0)
+#define CV(K) do { if (!LAST && F8P < 3) f8_cvt<PN, K>(st); } while (0)
+#define RD(R) do { if (F8P < 2 || (R < 2 && F8P < 5)) sch_red_load1<PAR, R>(st); } while (0)
+#else
 #define PKB(K) do { if (!LAST) f8_pkb<K>(st); } while (0)
 #define CV(K) do { if (!LAST) f8_cvt<PN, K>(st); } while (0)
 #define RD(R) sch_red_load1<PAR, R>(st)
+#endif
 #define LD() do { if (kLoadEven) sch_load_even<LSLOT>(st, load_addr); else if (kLoadOdd) sch_load_odd(st, load_addr); } while (0)
 #define HANDOFF() do { \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
