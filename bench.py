@@ -23,7 +23,9 @@ names 2^24 frames over 8 GPUs (2^21 per GPU): both are run by every rank as `ext
 
 roofline: the dominant kernel's algorithmic FLOPs (MFMA-bound nets) or bytes (HBM-bound
 nets) per launch / its mean launch duration, measured with HIP events recorded inside
-mdc_forward on the launch stream in a separate, untimed pass.
+mdc_forward on the launch stream in a separate, untimed pass.  roofline.traffic (VT-CNN2
+workloads, N = 1, default run): HBM bytes per launch from two rocprofv3 --pmc child passes of
+this very workload, run first (live_traffic); otherwise the committed profile's figure.
 cpu_baseline: the numpy oracle ("port": a CPU restatement, NOT Keras -- Keras/TensorFlow
 are not installed) timed on this box's host cores on a bounded sample; rank 0, N=1 only.
 """
@@ -99,6 +101,59 @@ def measured_traffic(key, frames_per_launch):
     return k["hbm_bytes_per_frame"] * frames_per_launch, f"profiles/{os.path.basename(files[-1])} (committed rocprofv3 PMC pass, bytes per frame x frames per launch; not measured in this run)"
 
 
+# rocprofv3 kernel-name substrings of the profiling slots, per dtype (tools/summarize_profiles.py uses the same ones)
+PMC_KERNELS = {"mdc_vt_conv": {"bf16": "vt_conv_bf16", "fp8": "vt_conv_fp8_kernel", "f32": "vt_conv_f32_kernel"},
+               "mdc_vt_dense1": {"bf16": "vt_dense1_bf16", "fp8": "vt_dense1_bf16", "f32": "vt_dense1_f32_kernel"}}
+LIVE_TRAFFIC = {}      # {"<slot>/<dtype>": (HBM bytes per launch, frames per launch)} measured by live_traffic() in THIS run
+
+
+def live_traffic(name, timeout_s=240):
+    """HBM bytes per launch of the workload's VT-CNN2 kernels, measured in THIS run: two child processes -- `rocprofv3 --pmc
+    FETCH_SIZE -- python3 bench.py --workload <name> --steps 2 ...` and the same with WRITE_SIZE, separate passes as
+    MI355X_MICROARCH.md's HBM section prescribes -- started BEFORE this process touches the GPU, their counter CSVs averaged
+    per kernel, corrected as the guide says (KiB -> bytes; gfx950's FETCH_SIZE reports half of a wide coalesced read: x 2).
+    Any failure (no rocprofv3, a refused or timed-out pass) leaves LIVE_TRAFFIC empty and the line falls back to the
+    committed profile's figure, saying so in traffic_source."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    kind, _f, _c, dtype, n, _w = WORKLOADS[name]
+    if kind != "vtcnn2" or shutil.which("rocprofv3") is None:
+        return
+    per_launch = min(n, 1 << 20) if dtype in ("bf16", "fp8") else min(n, 1 << 16)
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mdc_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
+                   "--workload", name, "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                print(f"[bench] live HBM-traffic pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                return
+            sums = {}
+            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if row.get("Counter_Name") != counter:
+                    continue
+                for slot, names in PMC_KERNELS.items():
+                    if names[dtype] in row["Kernel_Name"]:
+                        sums.setdefault(slot, []).append(float(row["Counter_Value"]))
+            for slot, v in sums.items():
+                got.setdefault(slot, {})[counter] = sorted(v)[len(v) // 2]      # median over the child's launches (all alike)
+        except Exception as e:      # noqa: BLE001 -- measurement garnish: never in the way of the timed run
+            print(f"[bench] live HBM-traffic pass {counter} failed: {e!r}", file=sys.stderr)
+            return
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    for slot, c in got.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            LIVE_TRAFFIC[f"{slot}/{dtype}"] = ((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, per_launch)
+
+
 def dominant_roofline(m, x, probs, labels, steps):
     """Untimed profiling pass: per-kernel HIP-event time -> roofline object of the dominant kernel."""
     import torch
@@ -122,7 +177,12 @@ def dominant_roofline(m, x, probs, labels, steps):
                  "mdc_vt_head": 2 * 256 * topo.classes}[name] * frames_per_launch
         ach = flops / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[m.dtype]
-        traffic, tsrc = measured_traffic(f"{name}/{m.dtype}", frames_per_launch)
+        live = LIVE_TRAFFIC.get(f"{name}/{m.dtype}")
+        if live and live[1] == frames_per_launch:
+            traffic, tsrc = live[0], ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this workload "
+                                      "(bench.live_traffic), per launch, gfx950 corrections applied")
+        else:
+            traffic, tsrc = measured_traffic(f"{name}/{m.dtype}", frames_per_launch)
         rl = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
               "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
               "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
@@ -266,8 +326,8 @@ def run_workload(name, device, steps, warmup, dist=None, frames=None):
         labels = torch.empty((n,), dtype=torch.int32, device=x.device)
         chunk = launch_chunk(WORKLOADS[name][0], dtype, n)
         m.bench_chunk = chunk      # (the untimed profiling pass of dominant_roofline launches the same way)
-        m.forward_device(x[: min(n, 4096)], probs=probs[: min(n, 4096)], labels=labels[: min(n, 4096)])     # library + weights are usable
-        if chunk:
+        m._engine()                         # library loaded, model created, weights packed and uploaded (no launch: the
+        if chunk:                           # profiles average per kernel over this process's launches)
             m.reserve_workspace(chunk)      # the big allocation happens HERE, where a failure can still be agreed on
         torch.cuda.synchronize()
     except Exception as e:      # noqa: BLE001 -- reported below, on every rank
@@ -477,6 +537,8 @@ def main(argv=None, script=None):
     ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child passes (use the committed profile's figure)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -490,6 +552,11 @@ def main(argv=None, script=None):
         # never measure a different job than the one asked for and label it with a stderr note
         print(f"[bench] --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: refusing to run", file=sys.stderr)
         return 2
+
+    if world == 1 and not args.no_live_traffic and not args.no_extras:
+        # roofline.traffic of the headline's kernels, measured in this run -- child processes, BEFORE this one touches the GPU
+        # (a process that has initialised the GPU must not start another program on this pool)
+        live_traffic(args.workload)
 
     import torch
     dist = None

@@ -67,8 +67,12 @@ enum {
  * power of two; the ReLU then rides in the bf16 conversion's clamp bit): conv1 / conv2 activations of 2^32 (4.3e9)
  * and beyond saturate, those below 2^-94 flush to zero -- I/Q samples of order 1e-2 sit in the middle of that range.
  * MDC_KIND_DEPLOYED does the same with its conv taps and bias at MDC_F32 and MDC_BF16 (the ReLU rides in the second
- * fma's / the conversion's clamp bit; dense weights carry the 2^+32): identical bits inside that range, conv
- * activations of 2^32 and beyond saturate there instead of growing on (tests/test_deployed_gpu.py pins it).
+ * fma's / the conversion's clamp bit; dense weights carry the 2^+32): bit-identity to Keras' operation order holds for
+ * conv activations in [2^-94, 2^32) -- at 2^32 and beyond they saturate at 2^32 instead of growing on, below 2^-94 the
+ * scaled value is an f32 denormal (bits lost, then zero), and an Inf activation yields finite probabilities where Keras
+ * gives NaN (tests/test_deployed_gpu.py pins both ends).  The MDC_TAP_CONV / MDC_TAP_FLAT taps of the deployed nets come
+ * from a kernel that reads the UNSCALED table and rectifies with fmaxf: outside that range a tap and the probabilities of
+ * the same frame can disagree.
  * MDC_F16: MDC_KIND_DEPLOYED only -- as MDC_BF16 there, with IEEE f16 operands and the conv itself in packed f16
  * (11 significant bits instead of 8, but conv outputs must stay below 65,504).
  * MDC_FP8: MDC_KIND_VTCNN2 -- conv2 on the block-scaled e4m3 MFMA, its features handed to dense1 as E4M3 bytes (conv1

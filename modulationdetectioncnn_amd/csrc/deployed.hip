@@ -173,8 +173,11 @@ __device__ __forceinline__ float rows_sum(float m) {       // sum over the four 
 // capture starts at byte f * hop2 (hop2 = 256: disjoint frames; smaller: overlapping windows of a live stream, whose
 // bytes are then fetched from HBM once and re-read from cache); only 2-byte alignment of a window is assumed.
 // ReLU rides in the clamp bit of the conv's second fma (round 3): the fast kernel's table carries the conv taps and bias
-// times 2^-32 and the dense weights times 2^+32 -- exact powers of two: every product and every f32 sum is the same bits as
-// with fma, fma, v_max_f32 -- so a conv output is below 1 unless the true value exceeds 2^32, and
+// times 2^-32 and the dense weights times 2^+32 -- exact powers of two: for conv activations in [2^-94, 2^32) every product
+// and every f32 sum is the same bits as with fma, fma, v_max_f32 (outside: the scaled activation saturates at 1 = 2^32
+// true, loses bits as an f32 denormal below 2^-94 true, and an Inf activation comes out finite; the MDC_TAP_CONV / FLAT
+// kernel reads the UNSCALED table with fmaxf, so there tap and probabilities can disagree: include/mdc.h) -- so a conv
+// output is below 1 unless the true value exceeds 2^32, and
 // __builtin_amdgcn_fmed3f(fma(...), 0, 1) folds into `v_fma_f32 ... clamp` (hipcc folds it into the plain fma only: the
 // 10-filter net's packed path keeps its packed first fma and takes two clamped plain fmas per pair of positions).  One VALU
 // fewer per conv output: T1 -4.3 % (0.230 -> 0.220 ms per 2^20 frames), T2 the speed of round 2's re-associated "pivot" form

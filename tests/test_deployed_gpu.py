@@ -516,6 +516,44 @@ def test_activations_beyond_the_documented_range_saturate_at_2_pow_32():
     assert np.isfinite(p).all() and np.abs(p.sum(axis=1) - 1).max() < 1e-5
 
 
+def test_activations_below_the_documented_range_lose_bits_and_taps_say_so():
+    """ADVICE r3 / include/mdc.h: bit-identity to Keras' operation order holds for conv activations in [2^-94, 2^32).  The
+    lower end, pinned: with zero biases and frames around 2^-100 the product kernel's 2^-32-scaled activations are f32
+    denormals (or flushed) -- its dense output is within 2^-94 * sum|w| of the truth, not within f32 relative precision --
+    while the MDC_TAP_CONV kernel (unscaled table, fmaxf) still gives the activations to f32 precision: tap and
+    probabilities may disagree outside the range, as the header says.  An Inf sample yields FINITE probabilities (Keras: NaN)
+    and touches no other frame."""
+    topo = Topology.deployed(3, 3)
+    rng = np.random.default_rng(5)
+    ck = rng.normal(0, 0.5, (1, 2, 1, 3)).astype(np.float32)
+    cb = np.zeros(3, np.float32)
+    dk = rng.normal(0, 0.05, (774, 3)).astype(np.float32)
+    db = np.zeros(3, np.float32)
+    m = VTCNN2(topo)
+    m.set_weights([(ck, cb), (dk, db)])
+    x = (synthetic_frames(64, seed=4, sigma=1.0) * np.float32(2.0 ** -100)).astype(np.float32)
+    ref = O.forward_deployed(x.astype(np.float64), ck, cb, dk, db, dtype=np.float64)
+    conv = m.predict(x, tap="conv")
+    np.testing.assert_allclose(conv, ref["conv"], rtol=2e-6, atol=0)                  # the tap kernel: exact to f32 rounding
+    dense = m.predict(x, tap="dense")
+    assert np.isfinite(dense).all() and (dense >= 0).all()
+    bound = 2.0 ** -94 * float(np.abs(dk).sum(axis=0).max())
+    assert float(np.abs(dense - ref["dense"]).max()) <= bound                          # absolute, from the denormal grid
+    assert float(np.abs(ref["dense"]).max()) < 64 * bound                              # ... i.e. no relative precision is claimed here
+    # inside the range the same model is bit-level exact again
+    x2 = (x * np.float32(2.0 ** 40)).astype(np.float32)
+    ref2 = O.forward_deployed(x2.astype(np.float64), ck, cb, dk, db, dtype=np.float64)
+    np.testing.assert_allclose(m.predict(x2, tap="dense"), ref2["dense"], rtol=4e-6, atol=0)
+    # Inf: finite probabilities from the product kernel, neighbours untouched
+    xi = synthetic_frames(64, seed=4)
+    clean = m.predict(xi)
+    xi[7, 0, 5] = np.inf
+    p = m.predict(xi)
+    assert np.isfinite(p).all()
+    keep = np.arange(64) != 7
+    np.testing.assert_array_equal(p[keep], clean[keep])
+
+
 def test_conv_taps_of_both_signs_with_biases_and_saturating_inputs():
     """both signs of the second tap, biases of both signs and a saturating input scale"""
     topo = Topology.deployed(10, 3)

@@ -14,10 +14,10 @@ rm -rf $R/gpurun_out/prof_${TAG}_bench $R/gpurun_out/prof_${TAG}_bench_extras $R
 if [ "$2" != "dep" ]; then
 # the headline kernels at the headline launch size only (the extra legs launch the same kernels at other sizes -- one
 # window, 65,536 f32 frames -- which would mix into the per-kernel averages): --no-extras; the extras get their own file
-rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
-rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench_extras -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_bench_extras.log 2>&1
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-live-traffic > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_bench_extras -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-live-traffic > $R/gpurun_out/prof_${TAG}_bench_extras.log 2>&1
 echo "kernel stats done"
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-traffic"
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt -- $B > $R/gpurun_out/pmc_fetch_vt.log 2>&1
 rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_vt -- $B > $R/gpurun_out/pmc_write_vt.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA $P -d $R/gpurun_out/pmc_mfma_vt -- $B > $R/gpurun_out/pmc_mfma_vt.log 2>&1
@@ -25,7 +25,7 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLE
 # HBM traffic of the other two VT-CNN2 modes' kernels (fp8 conv2 at 2^20 frames, f32 at 65,536): bench.py's extra legs
 for W in "vtcnn2-c11-fp8-n2^20:fp8" "vtcnn2-c3-f32-n65536:f32"; do
   WL=${W%%:*}; SFX=${W##*:}
-  BW="python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+  BW="python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-traffic"
   rm -rf $R/gpurun_out/pmc_fetch_vt$SFX $R/gpurun_out/pmc_write_vt$SFX
   rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_vt$SFX -- $BW > $R/gpurun_out/pmc_fetch_vt$SFX.log 2>&1
   rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_vt$SFX -- $BW > $R/gpurun_out/pmc_write_vt$SFX.log 2>&1
