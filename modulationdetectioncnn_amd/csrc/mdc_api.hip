@@ -147,7 +147,6 @@ int mdc_create(const mdc_topology* topo, int device, mdc_model** out) {
             if (flag("MDC_DENSE1_PHASED", 0)) m->alt |= kAltDense1Simple;
             if (flag("MDC_DEP_F32_MFMA", 1)) m->alt |= kAltDepF32Mfma;
             if (flag("MDC_D1_FUSED_HEAD", 0)) m->alt |= kAltSeparateHead;
-            if (flag("MDC_D1_WREG", 1)) m->alt |= kAltDense1Wreg;
             if (const char* e = getenv("MDC_DEP_RING")) m->alt_ring = atoi(e);
         }
 #endif

@@ -70,8 +70,7 @@ __device__ __forceinline__ uint2 load8_unaligned(const unsigned char* p) {
 enum { kAltConvHipcc = 1,      // MDC_CONV_SCHED=0: the hipcc-scheduled statement of the bf16 conv kernel (vtcnn2_bf16.hip)
        kAltDense1Simple = 2,   // MDC_DENSE1_PHASED=0: one barrier per K-tile (the race screen of the phased kernel)
        kAltDepF32Mfma = 4,     // MDC_DEP_F32_MFMA=1: deployed nets' f32 dense layer on the f32 matrix pipe (deployed_f32m.hip)
-       kAltSeparateHead = 8,   // MDC_D1_FUSED_HEAD=0: dense2 + softmax as their own launch at every batch size
-       kAltDense1Wreg = 16 };  // MDC_D1_WREG=1: dense1 with its weight fragments straight from L2 into registers (slower)
+       kAltSeparateHead = 8 }; // MDC_D1_FUSED_HEAD=0: dense2 + softmax as their own launch at every batch size
 
 struct ProfSlot {
     const char* name;

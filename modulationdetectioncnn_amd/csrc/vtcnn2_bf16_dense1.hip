@@ -279,8 +279,10 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
     auto stage_unit = [&](int t, int unit, int b) {
         unsigned char* dst = smem + ((size_t)b * 4 + unit) * kUnitBytes + (wv * 2) * 1024;
         if constexpr (F8) {
-            if (unit == 0 || unit == 3) {      // E4M3 feature rows: 64 B per row and K-tile, one piece per wave
-                glds16_nt(src8[unit == 3] + (long)t * kBK, smem + ((size_t)b * 4 + unit) * kUnitBytes + wv * 1024);
+            if (unit == 0 || unit == 3) {      // E4M3 feature rows: 64 B per row and K-tile, one piece per wave.  NOT non-temporal:
+                // a row's 128-byte line holds TWO K-tiles, and with the streaming hint the second half came from HBM again
+                // (PMC: 19.1 KB/frame read against 10.6 algorithmic; 4.23 -> 4.0 ms without the hint, profiles/r04_d1f8_temporal_ab.log)
+                glds16(src8[unit == 3] + (long)t * kBK, smem + ((size_t)b * 4 + unit) * kUnitBytes + wv * 1024);
                 return;
             }
         }
@@ -455,167 +457,8 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
     d1_epilogue<HEAD>(acc, smem, row0, n, lane, wv, c1, hid, w2pack, n_out, probs, labels);
 }
 
-// ------------------------------------------------------------------------------------
-// vt_dense1_bf16_wreg_kernel (round 3) -- the same tiles, wave grid, fragments and per-accumulator k order (bit-identical
-// results), with the WEIGHT fragments taken straight from global memory (L2) into registers instead of through LDS:
-// the phased kernel moves 64 KiB per K-tile and CU by LDS-DMA and sits on that path's fill rate (section 4.3: its time does
-// not fall when the features come from L2); here only the 32 KiB of feature rows go through LDS-DMA (a ring of four K-tiles,
-// issued two tiles ahead: 8 KiB in flight per wave), a wave's eight weight fragments per K-tile (its 64 columns x 64 k:
-// 8 x global_load_dwordx4, 64 contiguous bytes per four lanes, the same lines for the two wave rows) arrive two phases
-// before their first MFMA, fragment reads from LDS drop from 24 to 16 per wave and tile, and ONE barrier per K-tile is left.
-// Quadrant order (a0,b0) (a1,b0) (a1,b1) (a0,b1): b0's registers are dead after phase 1 and take the next tile's b0 in
-// phase 2; b1's are dead after phase 3 and take this tile's b1 in phase 0 -- no second register set for B.
-// Every vector-memory operation is issued from inline asm and waited for by counted vmcnt (hipcc would otherwise drain
-// the ring, vtcnn2_bf16_common.h); per tile and wave, in issue order:
-//     phase 0: Lb1(t) x4      phase 2: Lb0(t+1) x4, D_a0(t+2) x2      phase 3: D_a1(t+2) x2
-//     wait W1 (phase 2, before the b1 MFMAs): vmcnt(6) retires Lb1(t);  wait W2 (end of phase 3): vmcnt(4) retires Lb0(t+1)
-//     and everything older -- the copies of tile t+1 included, which the barrier at the top of the next tile then publishes.
-// The loaded registers are tied to the wait statements ("+v"), so no use can move above its wait, and W2 sits before the
-// loop's back edge so that a register copy the compiler might place there reads landed data.
-// A ring slot is refilled (tile t+2 into the slot of t-2) after the barrier of tile t, i.e. after every wave has finished
-// tile t-1: no wave can still be reading it.
-// Measured (profiles/r03_d1_wreg_ab.log, r03_d1_wreg_probes.log): bit-identical and SLOWER, 6.4 against 4.27 ms per 2^20 frames.
-// The probes say why it cannot win in any form: with the weight loads removed altogether (-DD1W_NOB: stale registers, the
-// feature ring, fragment reads and MFMAs as here) the kernel takes 4.25 ms -- the phased kernel's time with TWICE the LDS-DMA
-// volume -- so the feature stream from HBM alone sets dense1's time, not the LDS-DMA path's fill rate; with the feature copies
-// removed (-DD1W_NOA) the weight loads two phases ahead cost 5.65 ms: L2 latency the eight waves of a tile all wait out
-// together.  Alternates build only (MDC_D1_WREG=1), screened for bit-identity by tools/ab_dense1.py.
-// ------------------------------------------------------------------------------------
-#if defined(MDC_ALTERNATES) || defined(MDC_ABLATIONS)
-__device__ __forceinline__ void glds16_async_nt(const void* gsrc, void* lds_wave_base) {      // read-once source
-    const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
-    asm volatile("global_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "{m0}"(l) : "memory");
-}
-constexpr int kWregRing = 4;                                   // K-tiles of feature rows in LDS
-constexpr size_t kDenseWregLds = (size_t)kWregRing * 2 * kUnitBytes;      // 128 KiB
-static_assert(kDenseHeadLds >= kDenseWregLds, "the fused-head form allocates the larger of the two");
-
-template <bool HEAD>
-__global__ __launch_bounds__(512) void vt_dense1_bf16_wreg_kernel(const unsigned short* __restrict__ feat, long n,
-                                                                  const unsigned short* __restrict__ w1t,   // [165][256][64]
-                                                                  const float* __restrict__ c1, float* __restrict__ hid,
-                                                                  const float* __restrict__ w2pack = nullptr, int n_out = 0,
-                                                                  float* __restrict__ probs = nullptr, int* __restrict__ labels = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [4 tiles][a0 unit, a1 unit][16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wv >> 2, wc = wv & 3;
-    const int fr = lane & 15, fg = lane >> 4;
-    const long row0 = (long)blockIdx.x * kBM;
-
-    // ---- feature staging: per unit this wave moves pieces 2wv and 2wv+1 (8 unit rows x 128 B each), as the phased kernel
-    const int srow = lane >> 3, spos = lane & 7;
-    const unsigned short* asrc[2][2];      // [unit a0 / a1][piece]
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int u = (wv * 2 + j) * 8 + srow;                 // unit row 0..127
-        const int sw = (spos ^ (u & 7)) * 8;                   // swizzled source chunk (LDS destination is linear)
-        const int arow_lo = 128 * (u >> 6) + (u & 63);         // tile row of the a0 unit; a1 = +64
-        long g0 = row0 + arow_lo, g3 = row0 + arow_lo + 64;
-        if (g0 >= n) g0 = n - 1;                               // rows past the end are computed, not stored
-        if (g3 >= n) g3 = n - 1;
-        asrc[0][j] = feat + g0 * (long)kFeat + sw;
-        asrc[1][j] = feat + g3 * (long)kFeat + sw;
-    }
-    auto stage_a = [&](int t, int unit) {
-        unsigned char* dst = smem + ((size_t)(t & (kWregRing - 1)) * 2 + unit) * kUnitBytes + (wv * 2) * 1024;
-        glds16_async_nt(asrc[unit][0] + (long)t * kBK, dst);
-        glds16_async_nt(asrc[unit][1] + (long)t * kBK, dst + 1024);
-    };
-    auto frag = [&](const unsigned char* unit_base, int u, int ks) {
-        return *reinterpret_cast<const bf16x8*>(unit_base + u * 128 + (((ks * 4 + fg) ^ (u & 7)) * 16));
-    };
-    auto read_a = [&](bf16x8 (&a)[4][2], int t, int unit) {
-        const unsigned char* base = smem + ((size_t)(t & (kWregRing - 1)) * 2 + unit) * kUnitBytes;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a[i][ks] = frag(base, 64 * wr + 16 * i + fr, ks);
-    };
-    // ---- weight fragments: column 64 wc + 16 j + fr (+32 for b1), k = 32 ks + 8 fg .. +7 of K-tile t
-    const unsigned short* bsrc0 = w1t + (long)(wc * 64 + fr) * kBK + fg * 8;      // b0; b1 = + 32 rows
-    u32x4 b0[2][2], b1[2][2];
-    auto load_b = [&](u32x4 (&bq)[2][2], int t, int half) {
-        const unsigned short* p = bsrc0 + (long)t * (kBN * kBK) + half * 32 * kBK;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[0][0]) : "v"(p) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(bq[0][1]) : "v"(p) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(bq[1][0]) : "v"(p) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:2112" : "=v"(bq[1][1]) : "v"(p) : "memory");
-    };
-#define D1_TIE(N, Q) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(Q[0][0]), "+v"(Q[0][1]), "+v"(Q[1][0]), "+v"(Q[1][1]) :: "memory")
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 a0[4][2], a1[4][2];
-    auto quadrant = [&](const bf16x8 (&a)[4][2], const u32x4 (&bq)[2][2], int i0, int j0) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], __builtin_bit_cast(bf16x8, bq[j][ks]), acc[i0 + i][j0 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // ---- prologue: feature rows of tiles 0 and 1 and b0 of tile 0, all landed
-    stage_a(0, 0); stage_a(0, 1); stage_a(1, 0); stage_a(1, 1);
-    load_b(b0, 0, 0);
-    load_b(b1, 0, 1);
-    D1_TIE(0, b0);
-    D1_TIE(0, b1);
-
-    for (int t = 0; t < kNT; ++t) {
-        __builtin_amdgcn_s_barrier();                  // tile t's feature rows: every wave waited for its own pieces (W2 / prologue)
-        const bool more1 = t + 1 < kNT, more2 = t + 2 < kNT;
-        // phase 0: quadrant (a0, b0)
-#ifndef D1W_NOB
-        load_b(b1, t, 1);
-#endif
-        read_a(a0, t, 0);
-        quadrant(a0, b0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 1: quadrant (a1, b0)
-        read_a(a1, t, 1);
-        quadrant(a1, b0, 4, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 2: quadrant (a1, b1)
-#ifndef D1W_NOB
-        if (more1) load_b(b0, t + 1, 0);
-#endif
-#ifndef D1W_NOA
-        if (more2) stage_a(t + 2, 0);
-#endif
-#if defined(D1W_NOB)
-        if (more2) D1_TIE(2, b1); else D1_TIE(0, b1);
-#elif defined(D1W_NOA)
-        D1_TIE(4, b1);
-#else
-        if (more2) D1_TIE(6, b1); else D1_TIE(0, b1);
-#endif
-        quadrant(a1, b1, 4, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 3: quadrant (a0, b1)
-#ifndef D1W_NOA
-        if (more2) stage_a(t + 2, 1);
-#endif
-        quadrant(a0, b1, 0, 2);
-#if defined(D1W_NOB)
-        if (more2) D1_TIE(4, b0); else D1_TIE(0, b0);
-#elif defined(D1W_NOA)
-        D1_TIE(0, b0);
-#else
-        if (more2) D1_TIE(4, b0); else D1_TIE(0, b0);
-#endif
-    }
-#undef D1_TIE
-    d1_epilogue<HEAD>(acc, smem, row0, n, lane, wv, c1, hid, w2pack, n_out, probs, labels);
-}
-#endif      // MDC_ALTERNATES || MDC_ABLATIONS
+// (Round 3's variant with the weight fragments taken straight from L2 into registers -- bit-identical, 6.4 against 4.27 ms,
+// profiles/r03_d1_wreg_ab.log -- screened nothing the one-barrier kernel does not and left the tree in round 4: HISTORY.md 4.3.)
 
 // ------------------------------------------------------------------------------------
 // Small batches (a single window, or a few): the 256-row tile above would run its 165 K-tiles on ONE CU with 1/16 or
@@ -858,21 +701,6 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
     if (m->alt & kAltSeparateHead) fuse_head = false;
 #endif
 #undef MDC_LAUNCH_D1
-#ifdef MDC_ALTERNATES
-    if (!f8 && (m->alt & kAltDense1Wreg)) {      // weight fragments straight from L2 into registers (bit-identical, slower; see the kernel)
-        if (fuse_head && (probs || labels)) {
-            MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_wreg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseHeadLds));
-            hipLaunchKernelGGL((vt_dense1_bf16_wreg_kernel<true>), grid, dim3(512), kDenseHeadLds, s, f, (long)n, w1t, c1, hid,
-                               static_cast<const float*>(m->d_pack[5]), (int)m->topo.classes, probs, labels);
-            if (fused) *fused = true;
-        } else {
-            MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_wreg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseWregLds));
-            hipLaunchKernelGGL((vt_dense1_bf16_wreg_kernel<false>), grid, dim3(512), kDenseWregLds, s, f, (long)n, w1t, c1, hid);
-        }
-        MDC_HIP(hipGetLastError());
-        return MDC_OK;
-    }
-#endif
 #define MDC_LAUNCH_PHASED(F) do { \
     if (fuse_head && (probs || labels)) { \
         MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<0, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseHeadLds)); \

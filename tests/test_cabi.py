@@ -39,9 +39,9 @@ def test_product_library_has_one_kernel_per_role_and_never_reads_the_environment
     assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", alt], capture_output=True, text=True, check=True).stdout
     strings_prod = subprocess.run(["strings", prod], capture_output=True, text=True, check=True).stdout
     strings_alt = subprocess.run(["strings", alt], capture_output=True, text=True, check=True).stdout
-    for env in ("MDC_DEP_PIVOT", "MDC_DEP_F32_MFMA", "MDC_CONV_SCHED", "MDC_DENSE1_PHASED", "MDC_D1_WREG"):
+    for env in ("MDC_DEP_PIVOT", "MDC_DEP_F32_MFMA", "MDC_CONV_SCHED", "MDC_DENSE1_PHASED", "MDC_D1_FUSED_HEAD"):
         assert env not in strings_prod, env
-    alternates = ("deployed_f32m_kernel", "vt_conv_bf16_kernel", "vt_dense1_bf16_kernel", "vt_dense1_bf16_wreg_kernel")
+    alternates = ("deployed_f32m_kernel", "vt_conv_bf16_kernel", "vt_dense1_bf16_kernel")
     for k in alternates:
         assert not re.search(r"\d+%s[IE]" % k, strings_prod), k          # (mangled: <length><name>)
         assert re.search(r"\d+%s[IE]" % k, strings_alt), k

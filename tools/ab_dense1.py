@@ -30,8 +30,7 @@ print("PROF", {k: round(v[0] / max(v[1], 1), 4) for k, v in m.read_profile().ite
 ''' % (ROOT, LOGN)
 VARIANTS = {"product (fused head)": ("product", {}),
             "alternates: head as its own launch": ("alternates", {"MDC_D1_FUSED_HEAD": "0"}),
-            "alternates: one-barrier dense1": ("alternates", {"MDC_DENSE1_PHASED": "0"}),
-            "alternates: weights from L2 into registers": ("alternates", {"MDC_D1_WREG": "1"})}
+            "alternates: one-barrier dense1": ("alternates", {"MDC_DENSE1_PHASED": "0"})}
 hashes = set()
 for rnd in range(ROUNDS):
     for name, (variant, env) in VARIANTS.items():
