@@ -107,7 +107,7 @@ PMC_KERNELS = {"mdc_vt_conv": {"bf16": "vt_conv_bf16", "fp8": "vt_conv_fp8_kerne
 LIVE_TRAFFIC = {}      # {"<slot>/<dtype>": (HBM bytes per launch, frames per launch)} measured by live_traffic() in THIS run
 
 
-def live_traffic(name, timeout_s=240):
+def live_traffic(name, timeout_s=120):
     """HBM bytes per launch of the workload's VT-CNN2 kernels, measured in THIS run: two child processes -- `rocprofv3 --pmc
     FETCH_SIZE -- python3 bench.py --workload <name> --steps 2 ...` and the same with WRITE_SIZE, separate passes as
     MI355X_MICROARCH.md's HBM section prescribes -- started BEFORE this process touches the GPU, their counter CSVs averaged
