@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The evaluation half of the reference's cnn.py (lines 198-264) on this library, call for call:
 
+    score = model.evaluate(X_test, Y_test, batch_size=batch_size)        cnn.py:153   -> VTCNN2.evaluate (mean categorical cross-entropy)
     test_Y_hat = model.predict(X_test, batch_size=batch_size)            cnn.py:198   -> VTCNN2.predict (numpy in, numpy out)
     conf[j, k] += 1 over the test set, row-normalised                     cnn.py:199-216 -> VTCNN2.confusion
     per-SNR confusion matrices and acc[snr] = cor / (cor + ncor)          cnn.py:228-259 -> VTCNN2.accuracy_by_snr (one forward, one launch)
@@ -58,6 +59,8 @@ def flatten(data):
 def evaluate(model, X_test, lbl, classes, batch_size=1024, results_path=None):
     Y_idx = np.array([classes.index(m) for m, _ in lbl], np.int32)         # Y_test one-hot -> index (cnn.py:205)
     test_SNRs = np.array([s for _, s in lbl])                               # cnn.py:231
+    score = model.evaluate(X_test, Y_idx, batch_size=batch_size)            # cnn.py:153 (the mean categorical cross-entropy)
+    print(score)                                                            # cnn.py:154
     test_Y_hat = model.predict(X_test, batch_size=batch_size)               # cnn.py:198
     confnorm = model.confusion(X_test, Y_idx, batch_size=batch_size)        # cnn.py:199-216
     acc, conf_by_snr = model.accuracy_by_snr(X_test, Y_idx, test_SNRs)      # cnn.py:228-259

@@ -176,6 +176,15 @@ int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, 
 int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, const int32_t* bin_dev, int64_t n,
                          int classes, int bins, int64_t* counts_dev, int64_t* bad_dev, void* hip_stream);
 
+/* score = model.evaluate(X_test, Y_test, ...)  (cnn.py:153; the reference compiles with loss='categorical_crossentropy' and
+ * no metric, so the score is the mean loss): *loss_sum_dev += sum over i of -log(clip(p_i[t_i] / sum_c p_i[c], 1e-7, 1 - 1e-7))
+ * with p_i = probs_dev[i*classes ..] (the softmax rows mdc_forward returned) and t_i = truth_dev[i] (the index of the
+ * one-hot row's 1) -- Keras' categorical_crossentropy on probabilities.  f64, caller-zeroed, accumulates across calls; the
+ * mean is loss_sum / n.  Labels outside [0,classes) are counted in *bad_dev (may be NULL) and add nothing.  classes <= 32.
+ * Runs on the current device.  Added in ABI 4 (additive). */
+int mdc_crossentropy(const float* probs_dev, const int32_t* truth_dev, int64_t n, int classes,
+                     double* loss_sum_dev, int64_t* bad_dev, void* hip_stream);
+
 /* Raw SDR bytes -> frames: iq_dev holds n frames of 128 interleaved unsigned 8-bit (I,Q) pairs (256 B/frame, the
  * RTL-SDR format of the front-end in the reference's README.md:5); x_dev (n,2,128) f32 receives
  * ((byte - 127.5) * scale) with I in row 0 and Q in row 1.  Runs on the current device. */

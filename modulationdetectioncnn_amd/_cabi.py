@@ -25,6 +25,7 @@ EXPORTS = [
     "mdc_profile_name", "mdc_profile_read", "mdc_profile_reset", "mdc_last_error", "mdc_destroy",
     "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax",
     "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8",
+    "mdc_crossentropy",
 ]
 ABI_VERSION = 4
 MDC_OPT_FP8_BF16_FEATURES = 1      # include/mdc.h: option bit in mdc_topology.reserved[0]
@@ -83,10 +84,11 @@ def lib(variant: str = "product") -> C.CDLL:
     L.mdc_iq_u8_windows.argtypes = [vp, i64, i64, C.c_float, vp, vp]
     L.mdc_predict_host.argtypes = [vp, vp, i64, vp, vp, i64]
     L.mdc_predict_host_iq_u8.argtypes = [vp, vp, i64, i64, C.c_float, vp, vp, i64]
+    L.mdc_crossentropy.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     for name in ("mdc_create", "mdc_num_layers", "mdc_layer_sizes", "mdc_set_weights", "mdc_finalize",
                  "mdc_forward", "mdc_set_profiling", "mdc_profile_slots", "mdc_profile_read", "mdc_profile_reset",
                  "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax", "mdc_forward_iq_u8",
-                 "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8"):
+                 "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8", "mdc_crossentropy"):
         getattr(L, name).restype = i32
     if L.mdc_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{os.path.basename(path)} ABI version {L.mdc_abi_version()} != {ABI_VERSION}; rebuild it")

@@ -2,6 +2,8 @@
 //   mdc_confusion        -- the C x C confusion counts of cnn.py:205-216 / 242-255 (conf[true][argmax] += 1) on the
 //                           device, so an evaluation over a sharded batch exchanges C*C integers, not N labels;
 //   mdc_confusion_binned -- the same per SNR bin (the loop of cnn.py:228-259) in ONE launch: a B x C x C histogram;
+//   mdc_crossentropy     -- the sum behind `score = model.evaluate(X_test, Y_test)` (cnn.py:153: the model is compiled with
+//                           loss='categorical_crossentropy' and no metric, so the score IS the mean loss);
 //   mdc_iq_u8_to_frames / mdc_iq_u8_windows
 //                        -- raw SDR samples (unsigned 8-bit interleaved I,Q, the format of the RTL-SDR front-end the
 //                           reference's README.md:5 describes) -> (n,2,128) f32 frames.
@@ -45,6 +47,34 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int* __restrict__ 
     }
 }
 
+// Keras' categorical_crossentropy on PROBABILITIES (the reference's model ends in Activation('softmax') + Reshape, so the loss
+// sees the softmax output, not logits): row scaled to sum 1, clipped to [1e-7, 1 - 1e-7], -log of the true class's entry.
+// f64 accumulation: per-thread partial, LDS tree per work-group, one atomic per work-group.
+__global__ __launch_bounds__(256) void crossentropy_kernel(const float* __restrict__ probs, const int* __restrict__ truth, long n, int C,
+                                                           double* __restrict__ loss_sum, unsigned long long* __restrict__ bad) {
+    __shared__ double part[256];
+    double acc = 0.0;
+    unsigned nbad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int t = truth[i];
+        if ((unsigned)t >= (unsigned)C) { ++nbad; continue; }
+        const float* row = probs + i * C;
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += row[c];
+        float p = row[t] / sum;
+        p = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+        acc -= (double)logf(p);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && part[0] != 0.0) atomicAdd(loss_sum, part[0]);
+    if (bad && nbad) atomicAdd(bad, (unsigned long long)nbad);
+}
+
 // one thread = 4 consecutive bytes of a window = samples (I[2k], Q[2k], I[2k+1], Q[2k+1]); writes two floats to each
 // row.  Window f starts at byte 2*hop*f of the capture (hop = 128: disjoint frames); an odd hop leaves the 4 bytes only
 // 2-byte aligned, so they are fetched as two 16-bit loads then.
@@ -81,6 +111,17 @@ int confusion_launch(const int32_t* truth, const int32_t* pred, const int32_t* b
                            classes, bins, c, b);
     else
         hipLaunchKernelGGL(confusion_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, truth, pred, bin, (long)n, classes, bins, c, b);
+    MDC_HIP(hipGetLastError());
+    return MDC_OK;
+}
+
+int crossentropy_launch(const float* probs, const int32_t* truth, int64_t n, int classes, double* loss_sum, int64_t* bad, hipStream_t s) {
+    if (classes < 1 || classes > kMaxConfClasses) { set_error("mdc_crossentropy: classes must be 1..%d (got %d)", kMaxConfClasses, classes); return MDC_EINVAL; }
+    if (n == 0) return MDC_OK;
+    long grid = (n + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(crossentropy_kernel, dim3((unsigned)grid), dim3(256), 0, s, probs, truth, (long)n, classes, loss_sum,
+                       reinterpret_cast<unsigned long long*>(bad));
     MDC_HIP(hipGetLastError());
     return MDC_OK;
 }

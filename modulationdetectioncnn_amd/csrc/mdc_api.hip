@@ -321,6 +321,15 @@ int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, cons
         return confusion_launch(truth_dev, pred_dev, bin_dev, n, classes, bins, counts_dev, bad_dev, static_cast<hipStream_t>(hip_stream)); });
 }
 
+int mdc_crossentropy(const float* probs_dev, const int32_t* truth_dev, int64_t n, int classes, double* loss_sum_dev, int64_t* bad_dev,
+                     void* hip_stream) {
+    if (n < 0) { set_error("mdc_crossentropy: negative count"); return MDC_EINVAL; }
+    if (n > 0 && (!probs_dev || !truth_dev)) { set_error("mdc_crossentropy: null probabilities or labels"); return MDC_EINVAL; }
+    if (!loss_sum_dev) { set_error("mdc_crossentropy: null loss accumulator"); return MDC_EINVAL; }
+    return guarded("mdc_crossentropy", [&]() -> int {
+        return crossentropy_launch(probs_dev, truth_dev, n, classes, loss_sum_dev, bad_dev, static_cast<hipStream_t>(hip_stream)); });
+}
+
 int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream) {
     if (n < 0) { set_error("mdc_iq_u8_to_frames: negative frame count"); return MDC_EINVAL; }
     if (n == 0) return MDC_OK;

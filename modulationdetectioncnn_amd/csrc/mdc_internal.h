@@ -174,6 +174,7 @@ int vtcnn2_fp8_conv(const mdc_model* m, const float* x, int64_t n, void* feat, h
 // eval_ops.hip
 int confusion_launch(const int32_t* truth, const int32_t* pred, const int32_t* bin, int64_t n, int classes, int bins, int64_t* counts,
                      int64_t* bad, hipStream_t s);
+int crossentropy_launch(const float* probs, const int32_t* truth, int64_t n, int classes, double* loss_sum, int64_t* bad, hipStream_t s);
 int iq_u8_launch(const uint8_t* iq, int64_t n, int64_t hop, float scale, float* x, hipStream_t s);
 int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs, int32_t* labels,
                      float* tap, int tap_kind, hipStream_t s);

@@ -417,6 +417,36 @@ class VTCNN2:
             raise ValueError(f"{nbad} labels lie outside [0, {Cn})")
         return counts
 
+    def evaluate(self, X, Y, batch_size: Optional[int] = None) -> float:
+        """``score = model.evaluate(X_test, Y_test, batch_size=...)`` (cnn.py:153): the reference compiles its model with
+        loss='categorical_crossentropy' and no metric, so the score is the MEAN LOSS -- Keras' categorical cross-entropy
+        on the softmax rows (row scaled to sum 1, clipped to [1e-7, 1 - 1e-7]).  Y: one-hot rows (n, C) as cnn.py:80-82
+        builds them, or class indices (n,).  One forward, one reduction launch (mdc_crossentropy), one scalar read-back."""
+        torch = _torch()
+        Xt = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(X), dtype=np.float32)).to(f"cuda:{self.device_index}")
+        probs = self.predict(Xt, batch_size)
+        dev = probs.device
+        y = Y if isinstance(Y, torch.Tensor) else torch.as_tensor(np.asarray(Y))
+        if y.ndim == 2:
+            if tuple(y.shape) != tuple(probs.shape):
+                raise ValueError(f"one-hot targets have shape {tuple(y.shape)}, predictions {tuple(probs.shape)}")
+            y = y.argmax(dim=1)
+        truth = y.to(device=dev, dtype=torch.int32).contiguous()
+        if truth.shape != (probs.shape[0],):
+            raise ValueError(f"targets have shape {tuple(truth.shape)}, predictions {tuple(probs.shape)}")
+        n, Cn = probs.shape
+        if n == 0:
+            return float("nan")
+        loss = torch.zeros((1,), dtype=torch.float64, device=dev)
+        bad = torch.zeros((1,), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            self._check(self._lib().mdc_crossentropy(probs.data_ptr(), truth.data_ptr(), n, Cn, loss.data_ptr(), bad.data_ptr(),
+                                                     torch.cuda.current_stream(dev).cuda_stream))
+        both = torch.cat([loss, bad.to(torch.float64)]).cpu().numpy()      # the one synchronising read
+        if int(both[1]):
+            raise ValueError(f"{int(both[1])} labels lie outside [0, {Cn})")
+        return float(both[0] / n)
+
     def confusion(self, X, labels_true, batch_size: Optional[int] = None, normalize: bool = True) -> np.ndarray:
         """``conf[j,k] += 1`` over (true j, predicted k) then row-normalise, as cnn.py:199-216 does with the
         output of ``model.predict``; rows without samples stay 0."""

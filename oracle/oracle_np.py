@@ -173,6 +173,19 @@ def forward(kind: str, x, weights, dtype=np.float32, **kw) -> Dict[str, np.ndarr
     raise ValueError(kind)
 
 
+def categorical_crossentropy(probs: np.ndarray, labels_true: np.ndarray) -> float:
+    """``model.evaluate`` of the reference (cnn.py:113 compiles with loss='categorical_crossentropy', no metrics; :153 prints
+    the score): Keras 2.4's categorical_crossentropy on PROBABILITIES -- the model ends in Activation('softmax') followed
+    by Reshape, so the loss is handed the softmax output, not logits -- i.e. each row divided by its sum, clipped to
+    [1e-7, 1 - 1e-7] (K.epsilon()), minus the log of the true class's entry; mean over the samples.  f32 arithmetic per
+    row as TensorFlow's, f64 mean."""
+    p = np.asarray(probs, np.float32)
+    t = np.asarray(labels_true).astype(np.int64)
+    p = p / p.sum(axis=-1, keepdims=True, dtype=np.float32)
+    p = np.clip(p, np.float32(1e-7), np.float32(1.0) - np.float32(1e-7))
+    return float(np.mean(-np.log(p[np.arange(len(t)), t]).astype(np.float64)))
+
+
 def confusion(labels_true: np.ndarray, labels_pred: np.ndarray, classes: int) -> np.ndarray:
     """cnn.py:199-216: conf[j,k] += 1 then row-normalise (rows with no samples stay 0)."""
     conf = np.zeros((classes, classes), np.float64)

@@ -291,3 +291,51 @@ def test_one_process_multi_stream_driver_on_one_gpu():
         p, l = msp.predict(x.cpu().numpy())
         np.testing.assert_array_equal(p, ref_p.cpu().numpy())
         np.testing.assert_array_equal(l, ref_l.cpu().numpy())
+
+
+@pytest.mark.parametrize("kind,n", [("t1", 1), ("t1", 4097), ("t1", 200003), ("vtcnn2", 3000)])
+def test_evaluate_is_keras_categorical_crossentropy(kind, n):
+    """`score = model.evaluate(X_test, Y_test)` (cnn.py:153): the mean categorical cross-entropy of the softmax rows, Keras'
+    way (row / sum, clip to [1e-7, 1 - 1e-7], -log of the true entry) -- mdc_crossentropy against the numpy restatement on
+    the SAME probabilities, and one-hot targets (cnn.py:80-82) == index targets.  Parity unpinned against the recorded
+    0.5455 of CNN.ipynb cell 9 (the dataset it was computed on is not available)."""
+    from oracle import oracle_np as O
+    if kind == "t1":
+        m, C = _t1(), 3
+        x = synthetic_frames(n, seed=13, device="cuda") * 6.0          # all three classes occur, some rows saturate
+    else:
+        m, C = VTCNN2.synthetic(Topology.vtcnn2(11), seed=2016, dtype="bf16"), 11
+        x = synthetic_frames(n, seed=13, device="cuda")
+    truth = np.random.default_rng(2).integers(0, C, size=n).astype(np.int32)
+    p = m.predict(x).cpu().numpy()
+    want = O.categorical_crossentropy(p, truth)
+    got = m.evaluate(x, truth)
+    assert got == pytest.approx(want, rel=2e-6)
+    onehot = np.zeros((n, C))
+    onehot[np.arange(n), truth] = 1
+    assert m.evaluate(x.cpu().numpy(), onehot, batch_size=1024) == pytest.approx(want, rel=2e-6)
+    # the clip: a row that puts (almost) nothing on the true class costs -log(1e-7), not infinity
+    hard = p.argmin(axis=1).astype(np.int32)
+    capped = m.evaluate(x, hard)
+    assert np.isfinite(capped) and capped <= -np.log(1e-7) * (1 + 1e-6)
+    assert capped == pytest.approx(O.categorical_crossentropy(p, hard), rel=2e-6)
+    with pytest.raises(ValueError):
+        m.evaluate(x, np.full(n, C, np.int32))
+
+
+def test_crossentropy_entry_point_accumulates_and_validates():
+    from modulationdetectioncnn_amd import _cabi
+    L = _cabi.lib()
+    p = torch.tensor([[0.5, 0.25, 0.25], [0.1, 0.8, 0.1]], dtype=torch.float32, device="cuda")
+    t = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for _ in range(3):                                                  # caller-zeroed, accumulates across calls (shards)
+        _cabi.check(L.mdc_crossentropy(p.data_ptr(), t.data_ptr(), 2, 3, acc.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    assert float(acc.item()) == pytest.approx(3 * (-np.log(0.5) - np.log(0.8)), rel=1e-6)
+    L.mdc_last_error.restype = __import__("ctypes").c_char_p
+    assert L.mdc_crossentropy(p.data_ptr(), t.data_ptr(), -1, 3, acc.data_ptr(), None, None) == -22
+    assert L.mdc_crossentropy(None, t.data_ptr(), 2, 3, acc.data_ptr(), None, None) == -22
+    assert L.mdc_crossentropy(p.data_ptr(), t.data_ptr(), 2, 3, None, None, None) == -22
+    assert L.mdc_crossentropy(p.data_ptr(), t.data_ptr(), 2, 99, acc.data_ptr(), None, None) == -22 and b"classes" in L.mdc_last_error()
+    assert L.mdc_crossentropy(None, None, 0, 3, acc.data_ptr(), None, None) == 0

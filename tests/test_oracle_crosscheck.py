@@ -123,3 +123,25 @@ def test_theano_kernel_flip_is_a_true_convolution():
     wd = synthetic_weights(Topology.deployed(3, 3), seed=1)
     d.set_weights(wd, theano_kernels=True)
     np.testing.assert_array_equal(d.get_weights()[0][0], wd[0][0][::-1, ::-1])
+
+
+def test_categorical_crossentropy_is_keras_formula():
+    """oracle_np.categorical_crossentropy (the checker of VTCNN2.evaluate, cnn.py:153) against the formula written out, and
+    against torch's NLL on the same clipped probabilities."""
+    import torch
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(3)
+    z = rng.normal(0, 3, (500, 5)).astype(np.float32)
+    p = O.softmax(z)
+    p[0] = [1, 0, 0, 0, 0]                                   # a saturated row: the clip decides
+    t = rng.integers(0, 5, size=500)
+    t[0] = 1
+    want = 0.0
+    for i in range(500):
+        q = p[i] / p[i].sum()
+        want += -np.log(min(max(float(q[t[i]]), 1e-7), 1 - 1e-7))
+    want /= 500
+    got = O.categorical_crossentropy(p, t)
+    assert got == pytest.approx(want, rel=1e-6)
+    pt = torch.from_numpy(p / p.sum(axis=1, keepdims=True)).clamp(1e-7, 1 - 1e-7)
+    assert got == pytest.approx(float(torch.nn.functional.nll_loss(pt.log(), torch.from_numpy(t))), rel=1e-5)
