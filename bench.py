@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0                                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}  # dense MFMA peaks (no sparsity)
 PEAK_VALU_F32_TFLOPS = 157.3                                 # same guide: vector f32 peak (= the f32 matrix rate)
-# deployed legs whose bounding roof is the f32 vector ALU, not HBM (DESIGN.md 4.1: the 10-filter net at every dtype's
+# deployed legs whose bounding roof is the f32 vector ALU, not HBM (DESIGN.md 5.1 / 5.2: the 10-filter net at every dtype's
 # conv, the 3-filter net once its input is 256 B of raw bytes): they report bound = "valu" with the HBM fraction beside it
 VALU_BOUND = {("deployed", 10, "f32", "frames"), ("deployed", 10, "f32", "u8"), ("deployed", 3, "f32", "u8"),
               ("deployed", 10, "bf16", "frames"), ("deployed", 10, "f16", "frames")}

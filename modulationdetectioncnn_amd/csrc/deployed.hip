@@ -194,7 +194,7 @@ __device__ __forceinline__ float rows_sum(float m) {       // sum over the four 
 // groups stay in flight per wave across group AND block boundaries (the direct-load form drains at every block start);
 // groups past the wave's last one are clamped copies of it, so the count of outstanding copies stays uniform, and the
 // wave drains with vmcnt(0) before it ends (a copy must not land in LDS that already belongs to another work-group).
-// Round 2 tried this ring with the builtin and saw no gain: hipcc put a vmcnt(0) in front of every LDS read (DESIGN.md
+// Round 2 tried this ring with the builtin and saw no gain: hipcc put a vmcnt(0) in front of every LDS read (HISTORY.md
 // 4.1b, "the LDS-DMA rings were not rings").
 template <int F, int TAP, int ABL = 0, bool TAIL = false, bool U8 = false, int RING = 0>   // TAP: 0 none, 2 dense (model2); ABL: timing-only ablations
 __global__ __launch_bounds__(256) void deployed_fwd_kernel(const float* __restrict__ x, long n,
@@ -548,7 +548,7 @@ int deployed_forward(const mdc_model* m, const float* x, int64_t n, float* probs
     ProfScope ps(m, 0, s);
     // Alternates build only (MDC_DEP_F32_MFMA=1 when the model was created): the variant with Dense(3) on the f32 matrix
     // pipe (deployed_f32m.hip: same results to the last bits of the summation order, measured SLOWER -- v_mfma_f32_4x4x1
-    // holds the SIMD's vector issue for its whole 8 cycles); the production f32 path is the
+    // holds the SIMD's vector issue for its whole 8 cycles, HISTORY.md section 4.1c); the production f32 path is the
     // all-VALU kernel below.  Conv/flat taps always use the simple one-frame-at-a-time kernel.
 #ifdef MDC_ALTERNATES
     if (!tap_conv && f32_mfma_variant(m)) return deployed_f32m_forward(m, x, n, probs, labels, tap_dense, s);

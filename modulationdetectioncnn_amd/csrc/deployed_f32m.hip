@@ -30,7 +30,7 @@
 // U8 = true (mdc_forward_iq_u8): x points at raw interleaved unsigned 8-bit (I,Q) pairs, window f at byte f*hop2; a
 // frame is then 256 B (16 lanes of one DMA instruction), a lane reads the 32 bytes that hold its 16 samples of BOTH rows
 // and converts the row it owns with the arithmetic of iq_u8_kernel (eval_ops.hip): bit-identical to convert-then-forward.
-#ifdef MDC_ALTERNATES      // measured slower than the all-VALU kernel: test build only, not in libmdc.so
+#ifdef MDC_ALTERNATES      // measured slower than the all-VALU kernel (HISTORY.md 4.1c): test build only, not in libmdc.so
 #include "vtcnn2_bf16_common.h"
 
 #include <cstdlib>

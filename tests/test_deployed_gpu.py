@@ -291,7 +291,7 @@ def test_16bit_modes_keep_an_out_of_range_frame_to_itself(dtype):
 
 # ---------------------------------------------------------------------------------------------------------------
 # The f32 variant with Dense(3) on the f32 matrix pipe (csrc/deployed_f32m.hip): same bar as the production f32 kernel.
-# It is kept as the measured answer to "can the dense layer leave the VALU at f32?" (DESIGN.md section 4.1c): correct to
+# It is kept as the measured answer to "can the dense layer leave the VALU at f32?" (HISTORY.md section 4.1c): correct to
 # the same tolerances, slower -- so it lives in the alternates test build only (libmdc_alt.so, -DMDC_ALTERNATES), where
 # mdc_create reads MDC_DEP_F32_MFMA=1 once per model.
 @pytest.fixture
@@ -304,7 +304,7 @@ def f32_mfma(monkeypatch):
 @pytest.mark.parametrize("ring", [2, 3, 4, 6, 8])
 def test_lds_dma_ring_form_of_the_t1_kernel_is_bit_identical(monkeypatch, ring):
     """Round 3: T1's f32 kernel fed through a per-wave LDS-DMA ring (asm-issued copies, counted vmcnt)
-    instead of direct loads -- measured slower at every depth, so it lives in the alternates build; its
+    instead of direct loads -- measured slower at every depth (HISTORY.md 4.1), so it lives in the alternates build; its
     results must be the product's bits: full blocks through the ring, the ragged tail through the tail form, more blocks
     than waves and fewer."""
     monkeypatch.setenv("MDC_DEP_RING", str(ring))
