@@ -151,6 +151,12 @@ def test_fp8_feature_formats():
         assert on_grid.all() == (not bf), (bf, on_grid.mean())      # (e4m3 subnormals are on that grid too; bf16 features are not)
         ferr = float(np.abs(flat - ref["flat"][:64]).max() / np.abs(ref["flat"][:64]).max())
         errs[("flat", bf)] = ferr
+        # the batch kernels (n > 2,048: asm conv loop, phased dense1 with the fused head) and the small-batch forms
+        # (position-range conv, per-wave / four-wave dense1) of THIS feature format give the same bits
+        xb = synthetic_frames(5000, seed=22, device="cuda")
+        big = m.predict(xb)
+        for k in (1, 200, 1500):
+            assert torch.equal(big[:k], m.predict(xb[:k].contiguous())), (bf, k)
     assert errs[("flat", True)] < errs[("flat", False)] <= TOL["fp8"] + 1 / 16
     with pytest.raises(ValueError):
         VTCNN2(topo, dtype="bf16", fp8_bf16_features=True)
