@@ -214,8 +214,8 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, typename std
     f8_tap<PAR, 2, 3>(st, a2); FIN(9); FIN(10); PREP(0); PREP(1);
     f8_tap<PAR, 2, 4>(st, a2); FIN(11); PREP(2); PREP(3);
     // ---- C1: conv1(v+1), the only MFMAs that write VGPRs: no feature store next to them (vtcnn2_bf16_sched.hip)
-    C1M(0); FIN(12); FIN(14); FIN(13); WR(0);
-    C1M(1); FIN(15); FIN(16); FIN(17); WR(1);
+    C1M(0); WR(0); FIN(12); FIN(14); FIN(13);
+    C1M(1); WR(1); FIN(15); FIN(16); FIN(17);
     // ---- T1: tap 1; feature stores, the rest of the ds_writes (all five out by the third gap: the hand-off can then sit at
     //      the END of tap 1 and the partial reads finish a whole MFMA before the step does -- with the reads in the step's
     //      last gap, as in rounds 1-2, the next step's first wait exposed their latency: 23 % of the wave cycles were
