@@ -207,32 +207,28 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, typename std
     // 0.9857 on C = 11 noise frames) and is SLOWER: 16.25 ms with the six MFMAs spread between the fp8 ones, 15.8 clustered,
     // against 15.56 (profiles/r04_fp8_abs_form_*_ab.log): six small MFMAs cost what sixteen conversions cost.  Not kept
     // (the kernel file of that form: tools/experiments/vtcnn2_fp8_conv_absform.hip.txt).
+    // ORDER INSIDE A GAP (round 4, all bit-identical; profiles/r04_fp8_conv_gap_order*_ab.log): the memory instructions of a gap
+    // (ds_write / ds_read / global_store) FIRST, then its VALU -- 15.26 -> 14.2-14.4 ms from that alone, in three steps --; the
+    // e4m3 conversions never as the two halves of one dword back to back and never right behind the conversion that produced
+    // their source (hipcc puts an s_nop in front of either).  Measured and not better: memory and VALU alternating; the
+    // hand-off one or two gaps earlier; the partial writes two gaps earlier; the feature stores in memory-free gaps.
     // ---- T2: tap 2 -> a2 complete; finish of output v-1 (18 VALU, ReLU in the conversions' clamp bit), conv1 operand dwords of v+1
     f8_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); FIN(0); FIN(1); FIN(2);
     f8_tap<PAR, 2, 1>(st, a2); FIN(3); FIN(4); FIN(5);
     f8_tap<PAR, 2, 2>(st, a2); FIN(6); FIN(7); FIN(8);
     f8_tap<PAR, 2, 3>(st, a2); FIN(9); FIN(10); PREP(0); PREP(1);
     f8_tap<PAR, 2, 4>(st, a2); FIN(11); PREP(2); PREP(3);
-    // ---- C1: conv1(v+1), the only MFMAs that write VGPRs: no feature store next to them (vtcnn2_bf16_sched.hip)
     C1M(0); WR(0); FIN(12); FIN(14); FIN(13);
     C1M(1); WR(1); FIN(15); FIN(16); FIN(17);
-    // ---- T1: tap 1; feature stores, the rest of the ds_writes (all five out by the third gap: the hand-off can then sit at
-    //      the END of tap 1 and the partial reads finish a whole MFMA before the step does -- with the reads in the step's
-    //      last gap, as in rounds 1-2, the next step's first wait exposed their latency: 23 % of the wave cycles were
-    //      waits, profiles/r03_mfma.json), ReLU / fp8 pack of conv1(v+1) (units 0..7 read the first conv1 result block, two
-    //      long MFMAs behind its MFMA; 8..15 the second, four behind)
     f8_tap<PAR, 1, 0>(st, a1); ST(0); WR(2); PKB(0); PKB(1); PKB(2);
     f8_tap<PAR, 1, 1>(st, a1); ST(1); WR(3); PKB(3); PKB(4); PKB(5);
-    // (order of the e4m3 conversions: never the two halves of one dword back to back, never right behind the conversion that
-    // produced their source -- hipcc puts an s_nop in front of either, 13 per step before round 4)
-    f8_tap<PAR, 1, 2>(st, a1); WR(4); PKB(6); PKB(7); LD(); CV(0);
+    f8_tap<PAR, 1, 2>(st, a1); WR(4); LD(); PKB(6); PKB(7); CV(0);
     f8_tap<PAR, 1, 3>(st, a1); CV(2); CV(4); CV(6);
     f8_tap<PAR, 1, 4>(st, a1); CV(1); PKB(8); PKB(9); HANDOFF();
-    // ---- T0: tap 0 (fresh, C = bias); reads of partial(v), rest of the pack
-    f8_tap<PAR, 0, 0>(st, a0); RD(0); CV(3); RD(1); PKB(10); PKB(11);
-    f8_tap<PAR, 0, 1>(st, a0); RD(2); CV(5); RD(3); PKB(12); PKB(13);
-    f8_tap<PAR, 0, 2>(st, a0); RD(4); CV(7); CV(8); RD(5); PKB(14); PKB(15);
-    f8_tap<PAR, 0, 3>(st, a0); RD(6); CV(10); CV(12); CV(9); CV(14); RD(7);
+    f8_tap<PAR, 0, 0>(st, a0); RD(0); RD(1); CV(3); PKB(10); PKB(11);
+    f8_tap<PAR, 0, 1>(st, a0); RD(2); RD(3); CV(5); PKB(12); PKB(13);
+    f8_tap<PAR, 0, 2>(st, a0); RD(4); RD(5); CV(7); CV(8); PKB(14); PKB(15);
+    f8_tap<PAR, 0, 3>(st, a0); RD(6); RD(7); CV(10); CV(12); CV(9); CV(14);
     f8_tap<PAR, 0, 4>(st, a0); CV(11); CV(13); CV(15);
 #undef FIN
 #undef PREP
