@@ -173,7 +173,7 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
     sch_tap<PAR, 2, 19>(st, a2); PREP(3);
     // ---- C1: conv1(v+1): two 32x32x16 MFMAs, the only ones that write VGPRs.  Their 32-cycle gaps take two VALU and
     //      one LDS instruction each: end of the finish, first two ds_writes of partial(v).  NO feature store here (hazards)
-    C1M(0); FIN(16); FIN(17); WR(0);
+    C1M(0); WR(0); FIN(16); FIN(17);
     C1M(1); WR(1);
     // ---- T1: tap 1.  gaps: the two feature stores, three more ds_writes (the four waves share the CU's LDS store path,
     //      13 cycles per ds_write_b128: one every third gap keeps it unsaturated), pack of conv1(v+1) one VALU each
