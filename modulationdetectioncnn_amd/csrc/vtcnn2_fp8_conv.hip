@@ -210,16 +210,18 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, typename std
     // ORDER INSIDE A GAP (round 4, all bit-identical; profiles/r04_fp8_conv_gap_order*_ab.log): the memory instructions of a gap
     // (ds_write / ds_read / global_store) FIRST, then its VALU -- 15.26 -> 14.2-14.4 ms from that alone, in three steps --; the
     // e4m3 conversions never as the two halves of one dword back to back and never right behind the conversion that produced
-    // their source (hipcc puts an s_nop in front of either).  Measured and not better: memory and VALU alternating; the
-    // hand-off one or two gaps earlier; the partial writes two gaps earlier; the feature stores in memory-free gaps.
+    // their source (hipcc puts an s_nop in front of either); conv1's operand dwords (PREP) prepared in the first gaps, far ahead
+    // of the MFMA that reads them, and the finish's dependent tail (a, b -> t -> pack) not back to back (-0.7 %).  Measured and
+    // not better: memory and VALU alternating; the hand-off one or two gaps earlier; the partial writes two gaps earlier; the
+    // feature stores in memory-free gaps; the tile-4 words of the partial read pairwise (ds_read2st64_b32).
     // ---- T2: tap 2 -> a2 complete; finish of output v-1 (18 VALU, ReLU in the conversions' clamp bit), conv1 operand dwords of v+1
-    f8_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); FIN(0); FIN(1); FIN(2);
-    f8_tap<PAR, 2, 1>(st, a2); FIN(3); FIN(4); FIN(5);
-    f8_tap<PAR, 2, 2>(st, a2); FIN(6); FIN(7); FIN(8);
-    f8_tap<PAR, 2, 3>(st, a2); FIN(9); FIN(10); PREP(0); PREP(1);
-    f8_tap<PAR, 2, 4>(st, a2); FIN(11); PREP(2); PREP(3);
-    C1M(0); WR(0); FIN(12); FIN(14); FIN(13);
-    C1M(1); WR(1); FIN(15); FIN(16); FIN(17);
+    f8_tap<PAR, 2, 0, RANGE && (V12 == 1 || V12 == 2)>(st, a2); PREP(0); FIN(0); FIN(1);
+    f8_tap<PAR, 2, 1>(st, a2); PREP(1); FIN(2); FIN(3);
+    f8_tap<PAR, 2, 2>(st, a2); PREP(2); FIN(4); FIN(5);
+    f8_tap<PAR, 2, 3>(st, a2); PREP(3); FIN(6); FIN(7); FIN(8);
+    f8_tap<PAR, 2, 4>(st, a2); FIN(9); FIN(10); FIN(11);
+    C1M(0); WR(0); FIN(14); FIN(15); FIN(12);
+    C1M(1); WR(1); FIN(16); FIN(13); FIN(17);
     f8_tap<PAR, 1, 0>(st, a1); ST(0); WR(2); PKB(0); PKB(1); PKB(2);
     f8_tap<PAR, 1, 1>(st, a1); ST(1); WR(3); PKB(3); PKB(4); PKB(5);
     f8_tap<PAR, 1, 2>(st, a1); WR(4); LD(); PKB(6); PKB(7); CV(0);
