@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
     asm volatile("" : "+v"(a16), "+v"(b16));
     f32x2 p0 = f32x2{1.f, 2.f}, p1 = f32x2{3.f, 4.f}, p2, p3;
     float s0 = 1.f, s1 = 2.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
-    unsigned c0 = 0, c1 = 0;
+    unsigned c0 = 0, c1 = 0, u0 = 0, u1 = 0, u2 = 0;
     f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f};
     float r1 = 0.f;
     asm volatile("" : "+v"(p0), "+v"(p1), "+v"(s0), "+v"(s1));
@@ -97,6 +97,33 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
                 if (N > 2) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s4) : "v"(s0), "v"(s1), "v"(r1));
                 if (N > 3) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s5) : "v"(s0), "v"(s1), "v"(r1));
             }
+            // ---- round 4: what the fp8 conv step's gaps hold.  60+N: N x v_cvt_scalef32_pk_fp8_bf16; 65+N: N x v_cvt_pk_bf16_f32 clamp;
+            // 70 / 71: three v_add_f32 then a ds_read_b128 / the read first; 72 / 73: three VALU then 2 reads / the two reads first;
+            // 74 / 75: a ds_write_b128(agpr) behind / ahead of three v_add_f32; 76: 2 cvt_bf16 + 1 cvt_fp8 (a pack gap)
+            if (F >= 60 && F < 65) {
+                constexpr int N = F - 60;
+                if (N > 0) asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(c0) : "v"(c1), "v"(s0));
+                if (N > 1) asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(u0) : "v"(c1), "v"(s0));
+                if (N > 2) asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(u1) : "v"(c1), "v"(s0));
+                if (N > 3) asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(u2) : "v"(c1), "v"(s0));
+            }
+            if (F >= 65 && F < 70) {
+                constexpr int N = F - 65;
+                if (N > 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(c0) : "v"(s0), "v"(s1));
+                if (N > 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(u0) : "v"(s0), "v"(s1));
+                if (N > 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(u1) : "v"(s0), "v"(s1));
+                if (N > 3) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(u2) : "v"(s0), "v"(s1));
+            }
+#define G3ADD() do { asm volatile("v_add_f32 %0, %1, %2" : "=v"(s2) : "v"(s0), "v"(s1)); asm volatile("v_add_f32 %0, %1, %2" : "=v"(s3) : "v"(s0), "v"(s1)); \
+                     asm volatile("v_add_f32 %0, %1, %2" : "=v"(s4) : "v"(s0), "v"(s1)); } while (0)
+            if (F == 70) { G3ADD(); asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(lds_addr) : "memory"); }
+            if (F == 71) { asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(lds_addr) : "memory"); G3ADD(); }
+            if (F == 72) { G3ADD(); asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(lds_addr) : "memory"); asm volatile("ds_read_b32 %0, %1" : "=v"(r1) : "v"(lds_addr4) : "memory"); }
+            if (F == 73) { asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(lds_addr) : "memory"); asm volatile("ds_read_b32 %0, %1" : "=v"(r1) : "v"(lds_addr4) : "memory"); G3ADD(); }
+            if (F == 74) { G3ADD(); asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "a"(acc[(m + 2) % 5]) : "memory"); }
+            if (F == 75) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "a"(acc[(m + 2) % 5]) : "memory"); G3ADD(); }
+            if (F == 76) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(u0) : "v"(s0), "v"(s1)); asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(u1) : "v"(s0), "v"(s1));
+                           asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(c0) : "v"(c1), "v"(s0)); }
             if (F == 28) { asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(lds_addr) : "memory"); asm volatile("ds_read_b32 %0, %1" : "=v"(r1) : "v"(lds_addr4) : "memory"); }
             if (F == 29 && m == 0) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(s2) : "v"(s0), "v"(s1)); asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(p0), "s"(sbase) : "memory"); }
             if (F == 30) asm volatile("ds_read_b64 %0, %1" : "=v"(p2) : "v"(lds_addr8) : "memory");
@@ -121,10 +148,10 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(unsigned long long* out, fl
             if (F == 26) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(s2) : "v"(s0), "v"(s1)); asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(c0) : "v"(s0), "v"(s1)); }
             if (F == 27 && (m & 1) == 0) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(s2) : "v"(s0), "v"(s1)); asm volatile("v_add_f32 %0, %1, %2" : "=v"(s3) : "v"(s0), "v"(s1)); }
         }
-        if (F == 8 || F == 9 || F == 10 || F == 11 || F == 17 || F == 21 || F == 22 || F == 24 || F == 25 || F == 28 || F == 30) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1));
+        if (F == 8 || F == 9 || F == 10 || F == 11 || F == 17 || F == 21 || F == 22 || F == 24 || F == 25 || F == 28 || F == 30 || (F >= 70 && F <= 75)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1));
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
-    asm volatile("" ::"v"(p2), "v"(p3), "v"(c0), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(r0), "v"(r1), "v"(u64a));
+    asm volatile("" ::"v"(p2), "v"(p3), "v"(c0), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(r0), "v"(r1), "v"(u64a), "v"(u0), "v"(u1), "v"(u2));
     float keep = 0.f;
     for (int i = 0; i < 5; ++i) keep += acc[i][0];
     if (SMALL == 1) for (int i = 0; i < 8; ++i) { asm volatile("s_nop 7" : "+v"(xs[i])); keep += xs[i][0]; }
@@ -233,5 +260,21 @@ int main() {
     run<44, true, 3>("f8: 4 v_mov_b32 per gap", d_out, d_sink);
     run<49, true, 3>("f8: 4 v_med3 (1 vgpr src) per gap", d_out, d_sink);
     run<54, true, 3>("f8: 4 v_fma_f32 per gap", d_out, d_sink);
+    // ---- round 4: the fp8 conv step's gap contents (32-cycle fp8 MFMA gaps)
+    run<61, true, 3>("f8: 1 v_cvt_scalef32_pk_fp8_bf16 per gap", d_out, d_sink);
+    run<62, true, 3>("f8: 2 v_cvt_scalef32_pk_fp8_bf16 per gap", d_out, d_sink);
+    run<63, true, 3>("f8: 3 v_cvt_scalef32_pk_fp8_bf16 per gap", d_out, d_sink);
+    run<64, true, 3>("f8: 4 v_cvt_scalef32_pk_fp8_bf16 per gap", d_out, d_sink);
+    run<66, true, 3>("f8: 1 v_cvt_pk_bf16_f32 clamp per gap", d_out, d_sink);
+    run<67, true, 3>("f8: 2 v_cvt_pk_bf16_f32 clamp per gap", d_out, d_sink);
+    run<68, true, 3>("f8: 3 v_cvt_pk_bf16_f32 clamp per gap", d_out, d_sink);
+    run<69, true, 3>("f8: 4 v_cvt_pk_bf16_f32 clamp per gap", d_out, d_sink);
+    run<76, true, 3>("f8: 2 cvt_bf16 + 1 cvt_fp8 per gap", d_out, d_sink);
+    run<70, true, 3>("f8: 3 v_add THEN ds_read_b128 per gap", d_out, d_sink);
+    run<71, true, 3>("f8: ds_read_b128 THEN 3 v_add per gap", d_out, d_sink);
+    run<72, true, 3>("f8: 3 v_add THEN b128 + b32 reads per gap", d_out, d_sink);
+    run<73, true, 3>("f8: b128 + b32 reads THEN 3 v_add per gap", d_out, d_sink);
+    run<74, true, 3>("f8: 3 v_add THEN ds_write_b128 per gap", d_out, d_sink);
+    run<75, true, 3>("f8: ds_write_b128 THEN 3 v_add per gap", d_out, d_sink);
     return 0;
 }
