@@ -77,6 +77,37 @@ class Topology:
             return [((1, 2, 128, F), (F,)), ((3 * F, D), (D,)), ((D, C), (C,))]
         raise ValueError(self.kind)
 
+    def keras_layers(self) -> List[Tuple[str, Tuple[int, ...], int]]:
+        """The Sequential definition the reference writes down, layer by layer: (Keras-2 class name, output shape without
+        the batch axis, parameter count) -- what ``model.summary()`` prints (cnn.py:115; CNN.ipynb cell 6; the DeepSig
+        notebook :229-243, whose Keras-1 "Convolution2D" is Keras 2's Conv2D).  Derived from the topology alone: padding
+        widths from the kernel widths, conv outputs from 'valid' convolution over the padded input, channels_last for the
+        deployed nets and cnn.py's literal model, channels_first (Keras-1 / Theano ordering) for the canonical VT-CNN2.
+        tests/test_summaries.py holds every row against the tables stored in the reference's notebooks."""
+        F, D, C = self.filters, self.hidden, self.classes
+        if self.kind == "deployed":       # Reshape([2,128,1]) . ZeroPadding2D((0,1)) . Conv2D(F,(1,2)) . Flatten . Dense(C,relu) . softmax . Reshape([C])
+            return [("Reshape", (2, 128, 1), 0), ("ZeroPadding2D", (2, 130, 1), 0), ("Conv2D", (2, 130 - 2 + 1, F), (1 * 2 * 1 + 1) * F),
+                    ("Flatten", (2 * 129 * F,), 0), ("Dense", (C,), (2 * 129 * F + 1) * C), ("Activation", (C,), 0), ("Reshape", (C,), 0)]
+        if self.kind == "cnnpy":          # cnn.py:104-112 as TensorFlow reads it: (H, W, C) = (1, 2, 128)
+            return [("Reshape", (1, 2, 128), 0), ("ZeroPadding2D", (1, 4, 128), 0), ("Conv2D", (1, 4 - 2 + 1, F), (1 * 2 * 128 + 1) * F),
+                    ("Flatten", (3 * F,), 0), ("Dense", (D,), (3 * F + 1) * D), ("Dense", (C,), (D + 1) * C), ("Activation", (C,), 0),
+                    ("Reshape", (C,), 0)]
+        if self.kind == "vtcnn2":         # channels_first: (C, H, W)
+            return [("Reshape", (1, 2, 128), 0), ("ZeroPadding2D", (1, 2, 132), 0), ("Conv2D", (256, 2, 132 - 3 + 1), (1 * 1 * 3 + 1) * 256),
+                    ("Dropout", (256, 2, 130), 0), ("ZeroPadding2D", (256, 2, 134), 0), ("Conv2D", (80, 2 - 2 + 1, 134 - 3 + 1), (256 * 2 * 3 + 1) * 80),
+                    ("Dropout", (80, 1, 132), 0), ("Flatten", (80 * 132,), 0), ("Dense", (256,), (10560 + 1) * 256), ("Dropout", (256,), 0),
+                    ("Dense", (C,), (256 + 1) * C), ("Activation", (C,), 0), ("Reshape", (C,), 0)]
+        raise ValueError(self.kind)
+
+    def summary(self) -> str:
+        """A ``model.summary()``-style table (cnn.py:115) of keras_layers()."""
+        rows = self.keras_layers()
+        lines = ["Layer (type)                 Output Shape              Param #", "=" * 65]
+        for name, shape, params in rows:
+            lines.append(f"{name:<28} {str((None,) + tuple(shape)):<25} {params}")
+        lines += ["=" * 65, f"Total params: {sum(p for _, _, p in rows):,}"]
+        return "\n".join(lines)
+
     @property
     def flatten_order(self) -> str:
         return "channels_first" if self.kind == "vtcnn2" else "channels_last"

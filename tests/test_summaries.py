@@ -46,6 +46,27 @@ def test_layer_shapes_carry_keras_parameter_counts(tag):
     assert _rows(tag, PARAM_LAYERS)[-1]["output_shape"] == [topo.classes]
 
 
+@pytest.mark.parametrize("tag", sorted(TOPO))
+def test_the_whole_sequential_definition_matches_the_stored_table(tag):
+    """Topology.keras_layers() -- every layer of the definition, weighted or not, in order -- against the stored
+    model.summary() table row by row: class (Keras 1 printed "Convolution2D", Keras 2 truncates "ZeroPadding2D" to ten
+    characters), output shape, parameter count; and the total.  This is the reference-held pin of the T3 / T4 TOPOLOGIES."""
+    rows = TOPO[tag].keras_layers()
+    want = GOLD[tag]["layers"]
+    assert len(rows) == len(want)
+    for (name, shape, params), w in zip(rows, want):
+        printed = {"Convolution2D": "Conv2D"}.get(w["class"], w["class"])
+        assert name.startswith(printed), (name, w["class"])                 # "ZeroPaddin" is the truncated "ZeroPadding2D"
+        assert list(shape) == w["output_shape"], (name, shape, w["output_shape"])
+        assert params == w["params"], (name, params, w["params"])
+    assert sum(p for _, _, p in rows) == GOLD[tag]["total_params"]
+    text = TOPO[tag].summary()
+    assert f"Total params: {GOLD[tag]['total_params']:,}" in text and text.count("\n") == len(rows) + 3
+    # the weighted rows are the ones load_weights fills, in order
+    weighted = [(n, p) for n, _, p in rows if p]
+    assert [p for _, p in weighted] == [int(np.prod(k)) + int(np.prod(b)) for k, b in TOPO[tag].layer_shapes]
+
+
 def _keras_shapes(tag):
     """{our tap name: Keras' printed output shape}"""
     L = GOLD[tag]["layers"]
