@@ -9,8 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CASES = (  # (topology, dtype, frame counts): every small-batch form, the batch forms, the deployed LDS-DMA rings
-    ("vtcnn2", "bf16", (1, 16, 17, 64, 256, 1024, 1025, 2048, 5000)),
-    ("vtcnn2", "fp8", (1, 64, 256, 1024, 5000)),
+    # (1 << 18: every CU busy with full tiles, the LDS-DMA streams at their HBM rate -- where a hole in the phased dense1's
+    #  counted waits would show; fp8: the E4M3-feature form with its own wait counts)
+    ("vtcnn2", "bf16", (1, 16, 17, 64, 256, 1024, 1025, 2048, 5000, 1 << 18)),
+    ("vtcnn2", "fp8", (1, 64, 256, 1024, 5000, 1 << 18)),
     ("vtcnn2", "f32", (1, 128, 129, 2048)),
     ("deployed10", "bf16", (1, 1000, 70001)),
     ("deployed10", "f16", (70001,)),
