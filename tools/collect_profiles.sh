@@ -7,7 +7,7 @@
 # (gpurun_out/ is scratch): summarize_profiles.py stamps the round on what it copies into profiles/.
 set -e -o pipefail
 R=$PWD
-TAG=${1:-r02}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 P="--output-format csv"
 rm -rf $R/gpurun_out/prof_${TAG}_bench $R/gpurun_out/prof_${TAG}_bench_extras $R/gpurun_out/pmc_*_vt $R/gpurun_out/pmc_*_dep $R/gpurun_out/prof_${TAG}_dep
