@@ -107,6 +107,22 @@ PMC_KERNELS = {"mdc_vt_conv": {"bf16": "vt_conv_bf16", "fp8": "vt_conv_fp8_kerne
 LIVE_TRAFFIC = {}      # {"<slot>/<dtype>": (HBM bytes per launch, frames per launch)} measured by live_traffic() in THIS run
 
 
+def pmc_medians(csv_path, counter, dtype):
+    """{profiling slot: median Counter_Value over that kernel's dispatches} from one rocprofv3 *_counter_collection.csv
+    (columns Kernel_Name, Counter_Name, Counter_Value; one row per dispatch and counter).  The median, not the mean: a
+    child run's launches are all alike, and a stray small launch must not move the figure."""
+    import csv
+    vals = {}
+    with open(csv_path, newline="") as fd:
+        for row in csv.DictReader(fd):
+            if row.get("Counter_Name") != counter:
+                continue
+            for slot, names in PMC_KERNELS.items():
+                if names[dtype] in row.get("Kernel_Name", ""):
+                    vals.setdefault(slot, []).append(float(row["Counter_Value"]))
+    return {slot: sorted(v)[len(v) // 2] for slot, v in vals.items()}
+
+
 def live_traffic(name, timeout_s=120):
     """HBM bytes per launch of the workload's VT-CNN2 kernels, measured in THIS run: two child processes -- `rocprofv3 --pmc
     FETCH_SIZE -- python3 bench.py --workload <name> --steps 2 ...` and the same with WRITE_SIZE, separate passes as
@@ -114,7 +130,6 @@ def live_traffic(name, timeout_s=120):
     per kernel, corrected as the guide says (KiB -> bytes; gfx950's FETCH_SIZE reports half of a wide coalesced read: x 2).
     Any failure (no rocprofv3, a refused or timed-out pass) leaves LIVE_TRAFFIC empty and the line falls back to the
     committed profile's figure, saying so in traffic_source."""
-    import csv
     import glob
     import shutil
     import subprocess
@@ -135,15 +150,8 @@ def live_traffic(name, timeout_s=120):
             if r.returncode != 0 or not files:
                 print(f"[bench] live HBM-traffic pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
                 return
-            sums = {}
-            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
-                if row.get("Counter_Name") != counter:
-                    continue
-                for slot, names in PMC_KERNELS.items():
-                    if names[dtype] in row["Kernel_Name"]:
-                        sums.setdefault(slot, []).append(float(row["Counter_Value"]))
-            for slot, v in sums.items():
-                got.setdefault(slot, {})[counter] = sorted(v)[len(v) // 2]      # median over the child's launches (all alike)
+            for slot, v in pmc_medians(max(files, key=os.path.getmtime), counter, dtype).items():
+                got.setdefault(slot, {})[counter] = v
         except Exception as e:      # noqa: BLE001 -- measurement garnish: never in the way of the timed run
             print(f"[bench] live HBM-traffic pass {counter} failed: {e!r}", file=sys.stderr)
             return

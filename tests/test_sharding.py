@@ -389,3 +389,35 @@ def test_collective_device_follows_the_backend(monkeypatch):
     with pytest.raises(Exception):          # a meta tensor cannot come back to numpy: what matters is where it WENT
         sharding.confusion_counts(np.array([0, 1]), np.array([1, 1]), 3)
     assert seen == [("meta", "sum")]
+
+
+def test_bench_live_traffic_parsing_and_fallback(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic: the counter CSV of a rocprofv3 --pmc child pass is reduced per kernel slot by the MEDIAN
+    over dispatches (a stray small launch does not move it), a slot's bytes are (2 x FETCH_SIZE + WRITE_SIZE) KiB (the
+    guide's gfx950 correction), and without rocprofv3 nothing is recorded -- the line then falls back to the committed
+    profile's figure and says so."""
+    sys.path.insert(0, ROOT)
+    import bench
+    csv_path = tmp_path / "1_counter_collection.csv"
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    conv = '"void mdc::(anonymous namespace)::vt_conv_bf16_sched_kernel<0, false, false>(float const*, long)"'
+    d1 = '"void mdc::(anonymous namespace)::vt_dense1_bf16_phased_kernel<0, true, false>(unsigned short const*, long)"'
+    for i, v in enumerate([100.0, 525620.0, 525621.0, 525619.0, 525620.0]):          # one stray small launch
+        rows.append(f"{i},{i},1,1,1,1,65536,7,{conv},256,0,0,128,128,64,FETCH_SIZE,{v},0,1")
+    for i, v in enumerate([11152612.0, 11152610.0, 11152614.0]):
+        rows.append(f"{9 + i},{9 + i},1,1,1,1,65536,8,{d1},512,0,0,128,128,64,FETCH_SIZE,{v},0,1")
+    rows.append(f"20,20,1,1,1,1,65536,8,{d1},512,0,0,128,128,64,WRITE_SIZE,48.0,0,1")
+    csv_path.write_text("\n".join(rows) + "\n")
+    med = bench.pmc_medians(str(csv_path), "FETCH_SIZE", "bf16")
+    assert med == {"mdc_vt_conv": 525620.0, "mdc_vt_dense1": 11152612.0}
+    assert bench.pmc_medians(str(csv_path), "WRITE_SIZE", "bf16") == {"mdc_vt_dense1": 48.0}
+    assert bench.pmc_medians(str(csv_path), "FETCH_SIZE", "f32") == {}
+    # no rocprofv3 on PATH (this container's case is simulated explicitly): nothing recorded, no exception
+    monkeypatch.setattr(bench.shutil if hasattr(bench, "shutil") else __import__("shutil"), "which", lambda name: None)
+    bench.LIVE_TRAFFIC.clear()
+    bench.live_traffic("vtcnn2-c11-bf16-n2^20")
+    assert bench.LIVE_TRAFFIC == {}
+    bench.live_traffic("deployed3-f32-n2^20")                        # not a VT-CNN2 workload: nothing to do
+    assert bench.LIVE_TRAFFIC == {}
+    traffic, src = bench.measured_traffic("mdc_vt_conv/bf16", 1 << 20)
+    assert traffic is not None and "not measured in this run" in src and traffic / (1 << 20) == pytest.approx(22147, rel=2e-3)
