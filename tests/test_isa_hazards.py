@@ -24,7 +24,8 @@ def test_sched_kernel_has_no_store_vs_mfma_hazard(inst):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
-@pytest.mark.parametrize("inst", ["ILb0ELb0", "ILb1ELb0", "ILb0ELb1", "ILb1ELb1"])      # <U8, RANGE>
+@pytest.mark.parametrize("inst", ["ILb0ELb0ELb1", "ILb1ELb0ELb1", "ILb0ELb1ELb1", "ILb1ELb1ELb1",      # <U8, RANGE, F8OUT = E4M3 features>
+                                  "ILb0ELb0ELb0", "ILb1ELb0ELb0", "ILb0ELb1ELb0", "ILb1ELb1ELb0"])     # ... bf16 features (MDC_OPT_FP8_BF16_FEATURES)
 def test_fp8_kernel_has_no_store_vs_mfma_hazard(inst):
     spec = importlib.util.spec_from_file_location("lint_async_hazards", os.path.join(ROOT, "tools", "lint_async_hazards.py"))
     lint = importlib.util.module_from_spec(spec)
