@@ -142,7 +142,9 @@ def live_traffic(name, timeout_s=120):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mdc_pmc_", dir="/tmp")
         try:
-            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
+            # the program after `--` is THIS interpreter (sys.executable: never a PATH shim that would exec again inside a process
+            # the profiler has already GPU-initialised, and the one interpreter known to have torch)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--workload", name, "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-live-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
@@ -492,33 +494,78 @@ def select_device(device):
     torch.cuda.set_device(device)
 
 
+def rank_environment(env):
+    """What EVERY rank needs in its environment before it touches the GPU, whoever launched it (this file's own launcher
+    or the driver's torch.distributed.run): dmabuf IPC -- the host driver supports no other, and without it RCCL across
+    processes fails with `hipIpcGetMemHandle: invalid argument`."""
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def init_distributed(device, backend=None):
+    """One process per GPU: "nccl" IS RCCL on ROCm.  The rank's GPU is bound explicitly (device_id) so that RCCL builds its
+    communicator on THAT device at once instead of guessing from the first collective's tensor; gloo (the CPU rehearsal)
+    takes no device."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = backend or os.environ.get("MDC_BENCH_BACKEND", "nccl")
+    kw = {"device_id": torch.device("cuda", device)} if backend == "nccl" else {}
+    dist.init_process_group(backend, **kw)
+    return dist
+
+
 def self_launch(ngpu, argv, script):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the one-process-per-GPU job ourselves --
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P <script> <argv>`
     -- as a CHILD process (never exec: nothing here has touched the GPU, and nothing will in this parent), pass rank 0's
     JSON line through on stdout and return the child's exit code.  Works the same under the driver's own launcher,
     which sets WORLD_SIZE and never reaches this function."""
-    import socket
+    import signal
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env = rank_environment(dict(os.environ))
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpu}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script] + list(argv)
+    # --standalone: the launcher's own c10d store on a free port IT picks (no bind-then-close window for another process to
+    # take the port in); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={ngpu}", script] + list(argv)
     print(f"[bench] --gpus {ngpu} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+
+    def stop_child(grace=10.0):
+        """The launcher and its ranks form their own session: signal the whole group, so no rank outlives us holding a GPU."""
+        if child.poll() is not None:
+            return
+        for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(child.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                return
+            try:
+                child.wait(timeout=wait)
+                return
+            except subprocess.TimeoutExpired:
+                continue
+
+    def on_signal(signum, _frame):      # a driver's timeout (SIGTERM) or ^C reaches the ranks too
+        stop_child()
+        sys.exit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     lines = 0
-    for line in child.stdout:       # (the ranks' stderr goes straight through; their stdout carries rank 0's one line
-        if line.lstrip().startswith("{"):                   # and whatever a backend chats there, e.g. gloo's "[Gloo] Rank 0
-            lines += 1                                      # is connected ...": that goes to OUR stderr, so stdout is the line)
-            sys.stdout.write(line)
-            sys.stdout.flush()
-        else:
-            sys.stderr.write(line)
-    rc = child.wait()
+    try:
+        for line in child.stdout:       # (the ranks' stderr goes straight through; their stdout carries rank 0's one line
+            if line.lstrip().startswith("{"):                   # and whatever a backend chats there, e.g. gloo's "[Gloo] Rank 0
+                lines += 1                                      # is connected ...": that goes to OUR stderr, so stdout is the line)
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
+        rc = child.wait()
+    finally:
+        stop_child()
+        for sg, h in old.items():
+            signal.signal(sg, h)
     if rc == 0 and lines != 1:
         print(f"[bench] the {ngpu}-rank job printed {lines} JSON lines (expected 1)", file=sys.stderr)
         return 3
@@ -550,6 +597,7 @@ def main(argv=None, script=None):
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    rank_environment(os.environ)      # every rank, launched by whomever, BEFORE torch is imported or the GPU touched
 
     launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -569,15 +617,14 @@ def main(argv=None, script=None):
     import torch
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" IS RCCL on ROCm.  MDC_BENCH_BACKEND=gloo / MDC_BENCH_ONE_DEVICE=1 exist only to rehearse the
-        # N>1 control flow on a one-GPU box (all ranks share cuda:0); the driver's scaling run uses neither.
-        dist.init_process_group(os.environ.get("MDC_BENCH_BACKEND", "nccl"))
+        # MDC_BENCH_BACKEND=gloo / MDC_BENCH_ONE_DEVICE=1 exist only to rehearse the N>1 control flow on a one-GPU box (all
+        # ranks share cuda:0); the driver's scaling run uses neither.
         device = 0 if os.environ.get("MDC_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+        select_device(device)
+        dist = init_distributed(device)
     else:
         device = 0
-    select_device(device)
+        select_device(device)
     rank = dist.get_rank() if dist else 0
     ngpu = world if dist else 1
 

@@ -33,12 +33,21 @@
 extern "C" {
 #endif
 
-#define MDC_ABI_VERSION 4   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows
+/* libmdc.so is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols
+ * (tests/test_cabi.py compares `nm -D --defined-only` with this header, both ways). */
+#if defined(__GNUC__) || defined(__clang__)
+#define MDC_API __attribute__((visibility("default")))
+#else
+#define MDC_API
+#endif
+
+#define MDC_ABI_VERSION 5   /* 2: mdc_forward_iq_u8 takes hop + workspace; mdc_confusion_binned, mdc_iq_u8_windows
                                3: mdc_topology.reserved[0] is a validated option word (no bit defined: must be 0);
                                   mdc_iq_u8_windows wants 2-byte aligned input; the library reads no environment
                                4: MDC_KIND_VTCNN2 at MDC_FP8 keeps E4M3 features (its workspace per frame shrinks from
                                   22,144 to 11,584 bytes: ask mdc_workspace_bytes); MDC_OPT_FP8_BF16_FEATURES restores
-                                  ABI 3's numerics and workspace */
+                                  ABI 3's numerics and workspace
+                               5: the training step (mdc_trainer_*, mdc_train_batch): additive */
 
 /* error codes (negative errno values) */
 #define MDC_OK        0
@@ -111,28 +120,28 @@ typedef struct mdc_topology {
 
 typedef struct mdc_model mdc_model;   /* opaque, owned by the library */
 
-int mdc_abi_version(void);
+MDC_API int mdc_abi_version(void);
 
 /* models.Sequential() + model.add(...): describe the net.  `device` is the HIP ordinal. */
-int mdc_create(const mdc_topology* topo, int device, mdc_model** out);
+MDC_API int mdc_create(const mdc_topology* topo, int device, mdc_model** out);
 
 /* Number of weighted layers and the element counts load_weights must supply for each. */
-int mdc_num_layers(const mdc_model* m);
-int mdc_layer_sizes(const mdc_model* m, int layer, size_t* kernel_elems, size_t* bias_elems);
+MDC_API int mdc_num_layers(const mdc_model* m);
+MDC_API int mdc_layer_sizes(const mdc_model* m, int layer, size_t* kernel_elems, size_t* bias_elems);
 
 /* model.load_weights(): one call per weighted layer, host pointers in the Keras layout
  * (deployed/cnnpy conv: HWIO; vtcnn2 conv: OIHW; dense: (in, out) with `in` in the
  * reference's Flatten order).  The data is copied; the caller keeps ownership.            */
-int mdc_set_weights(mdc_model* m, int layer, const float* kernel_host, size_t kernel_elems,
+MDC_API int mdc_set_weights(mdc_model* m, int layer, const float* kernel_host, size_t kernel_elems,
                     const float* bias_host, size_t bias_elems);
 
 /* Pack the weights into the kernels' register/LDS/MFMA layouts and upload them.
  * After this the model is immutable.  dtype: MDC_F32 | MDC_BF16 | MDC_FP8. */
-int mdc_finalize(mdc_model* m, int dtype);
+MDC_API int mdc_finalize(mdc_model* m, int dtype);
 
 /* MDC_FP8 only, before mdc_finalize: the largest |I/Q sample| the caller will feed (default 0.02, the scale of the
  * reference's bundled frames).  It fixes the power-of-two scale of the fp8 activations. */
-int mdc_set_fp8_input_absmax(mdc_model* m, float absmax);
+MDC_API int mdc_set_fp8_input_absmax(mdc_model* m, float absmax);
 
 /* Bytes of caller-owned device scratch ONE mdc_forward call of n frames needs (0 for deployed / cnnpy).
  * MDC_KIND_VTCNN2 keeps a call's conv2 features there: n rounded up to 256 frames x (10,560 features x 2 B in the
@@ -141,12 +150,12 @@ int mdc_set_fp8_input_absmax(mdc_model* m, float absmax);
  * streams must not share a workspace.  A caller bounds it by splitting a batch into several calls (results do not
  * depend on the split; 65,536 frames per call already fill the chip 16 times over and cost 1.5 % against one
  * 2^20-frame call); modulationdetectioncnn_amd.VTCNN2 does that by default. */
-size_t mdc_workspace_bytes(const mdc_model* m, int64_t n);
+MDC_API size_t mdc_workspace_bytes(const mdc_model* m, int64_t n);
 
 /* model.predict(X) (+ np.argmax): x_dev (n,2,128) f32 contiguous on the model's device.
  * probs_dev (n,C) f32 or NULL; labels_dev (n) int32 or NULL (first-max tie-break);
  * tap_dev NULL unless tap != MDC_TAP_NONE.  Enqueued on hip_stream (NULL = null stream). */
-int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n,
+MDC_API int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n,
                 float* probs_dev, int32_t* labels_dev,
                 float* tap_dev, int tap,
                 void* workspace_dev, size_t workspace_bytes,
@@ -160,20 +169,20 @@ int mdc_forward(const mdc_model* m, const void* x_dev, int64_t n,
  * tables are made from the model's weights at mdc_finalize (float2fix: trunc(v * 4096)).
  * x_dev: (n,2,128) f32 frames (quantised on load, x_is_q612 = 0) or int32 Q6.12 words (x_is_q612 = 1).
  * dense_dev (n,C) int32 = post-ReLU class sums, value/4096 (or NULL); labels_dev (n) int32 first maximum (or NULL). */
-int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64_t n,
+MDC_API int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64_t n,
                      int32_t* dense_dev, int32_t* labels_dev, void* hip_stream);
 
 /* Confusion counts of cnn.py:205-216 / 242-255 on the device: counts_dev[t*classes + p] += 1 for every i with
  * truth_dev[i] == t and pred_dev[i] == p (int64, caller-zeroed, accumulates across calls).  Pairs with a label
  * outside [0,classes) are added to *bad_dev instead (may be NULL).  classes <= 32.  Runs on the current device. */
-int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, int classes,
+MDC_API int mdc_confusion(const int32_t* truth_dev, const int32_t* pred_dev, int64_t n, int classes,
                   int64_t* counts_dev, int64_t* bad_dev, void* hip_stream);
 
 /* The per-SNR evaluation loop of cnn.py:228-259 in ONE launch: bin_dev[i] in [0,bins) says which SNR (or any other
  * grouping) frame i belongs to, and counts_dev[(b*classes + t)*classes + p] += 1 -- a (bins, classes, classes) int64
  * histogram, caller-zeroed; acc[b] = trace / sum of slice b (cnn.py:257-259).  Entries with a label or bin out of
  * range go to *bad_dev (may be NULL).  classes <= 32, bins <= 65536.  Runs on the current device. */
-int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, const int32_t* bin_dev, int64_t n,
+MDC_API int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, const int32_t* bin_dev, int64_t n,
                          int classes, int bins, int64_t* counts_dev, int64_t* bad_dev, void* hip_stream);
 
 /* score = model.evaluate(X_test, Y_test, ...)  (cnn.py:153; the reference compiles with loss='categorical_crossentropy' and
@@ -182,19 +191,19 @@ int mdc_confusion_binned(const int32_t* truth_dev, const int32_t* pred_dev, cons
  * one-hot row's 1) -- Keras' categorical_crossentropy on probabilities.  f64, caller-zeroed, accumulates across calls; the
  * mean is loss_sum / n.  Labels outside [0,classes) are counted in *bad_dev (may be NULL) and add nothing.  classes <= 32.
  * Runs on the current device.  Added in ABI 4 (additive). */
-int mdc_crossentropy(const float* probs_dev, const int32_t* truth_dev, int64_t n, int classes,
+MDC_API int mdc_crossentropy(const float* probs_dev, const int32_t* truth_dev, int64_t n, int classes,
                      double* loss_sum_dev, int64_t* bad_dev, void* hip_stream);
 
 /* Raw SDR bytes -> frames: iq_dev holds n frames of 128 interleaved unsigned 8-bit (I,Q) pairs (256 B/frame, the
  * RTL-SDR format of the front-end in the reference's README.md:5); x_dev (n,2,128) f32 receives
  * ((byte - 127.5) * scale) with I in row 0 and Q in row 1.  Runs on the current device. */
-int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream);
+MDC_API int mdc_iq_u8_to_frames(const uint8_t* iq_dev, int64_t n, float scale, float* x_dev, void* hip_stream);
 
 /* Sliding windows over one contiguous capture (the live RTL-SDR stream of README.md:5): window i holds the 128 (I,Q)
  * pairs starting at pair i*hop, i.e. bytes [2*hop*i, 2*hop*i + 256) of iq_dev, which must hold 2*hop*(n-1) + 256 bytes.
  * hop = MDC_HOP_FRAME (128) is mdc_iq_u8_to_frames.  x_dev (n,2,128) f32.  Runs on the current device. */
 #define MDC_HOP_FRAME 128
-int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale, float* x_dev, void* hip_stream);
+MDC_API int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale, float* x_dev, void* hip_stream);
 /* (iq_dev 2-byte aligned -- whole (I,Q) pairs --, as mdc_forward_iq_u8 requires; otherwise MDC_EINVAL) */
 
 /* Conversion and forward in ONE pass, for the deployed nets (any of their dtypes) and the VT-CNN2 family (f32, bf16,
@@ -206,7 +215,7 @@ int mdc_iq_u8_windows(const uint8_t* iq_dev, int64_t n, int64_t hop, float scale
  * kernels use gfx950's unaligned global loads), 2*hop*(n-1) + 256 bytes.  probs_dev (n,C) f32 and labels_dev (n)
  * int32 may each be NULL.  workspace: as mdc_forward (mdc_workspace_bytes(m, n); NULL/0 for the deployed nets).
  * MDC_KIND_CNNPY: MDC_ENOTSUP (use the two calls).  This is the SDR -> classifier hand-off of README.md:5. */
-int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, int64_t hop, float scale,
+MDC_API int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, int64_t hop, float scale,
                       float* probs_dev, int32_t* labels_dev,
                       void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
@@ -219,12 +228,12 @@ int mdc_forward_iq_u8(const mdc_model* m, const uint8_t* iq_dev, int64_t n, int6
  * (each may be NULL) are complete.  Results are bit-identical to mdc_forward on the same frames, whatever the chunk.
  * Staging buffers, streams and the workspace belong to the model (created on first use, freed by mdc_destroy); calls
  * on one model are serialised.  Added in ABI 2 (additive). */
-int mdc_predict_host(mdc_model* m, const float* x_host, int64_t n, float* probs_host, int32_t* labels_host,
+MDC_API int mdc_predict_host(mdc_model* m, const float* x_host, int64_t n, float* probs_host, int32_t* labels_host,
                      int64_t chunk_frames);
 
 /* The same for raw uint8 I/Q in host memory (an SDR capture buffer, README.md:5): n windows, `hop` pairs apart, from
  * iq_host (2*hop*(n-1) + 256 bytes) through mdc_forward_iq_u8 -- 2*hop bytes per window over PCIe instead of 1,024. */
-int mdc_predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int64_t hop, float scale,
+MDC_API int mdc_predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int64_t hop, float scale,
                            float* probs_host, int32_t* labels_host, int64_t chunk_frames);
 
 /* Measurement support (bench.py roofline leg): when on, mdc_forward brackets each kernel
@@ -233,14 +242,76 @@ int mdc_predict_host_iq_u8(mdc_model* m, const uint8_t* iq_host, int64_t n, int6
  * mdc_profile_reset.  Off by default; never on in the timed region of the headline number.
  * Forwards may run concurrently with profiling on (the event lists are mutex-guarded); mdc_set_profiling /
  * mdc_profile_reset themselves must not race with forwards of the same model. */
-int mdc_set_profiling(mdc_model* m, int on);
-int mdc_profile_slots(const mdc_model* m);
-const char* mdc_profile_name(const mdc_model* m, int slot);
-int mdc_profile_read(mdc_model* m, int slot, double* total_ms, int64_t* launches);
-int mdc_profile_reset(mdc_model* m);
+MDC_API int mdc_set_profiling(mdc_model* m, int on);
+MDC_API int mdc_profile_slots(const mdc_model* m);
+MDC_API const char* mdc_profile_name(const mdc_model* m, int slot);
+MDC_API int mdc_profile_read(mdc_model* m, int slot, double* total_ms, int64_t* launches);
+MDC_API int mdc_profile_reset(mdc_model* m);
 
-const char* mdc_last_error(void);
-void mdc_destroy(mdc_model* m);
+/* ---- training -----------------------------------------------------------------------
+ * The reference trains two nets: CNN.ipynb cell 6's (MDC_KIND_DEPLOYED; the five bundled .h5 files are its results) and
+ * cnn.py:104-112's (MDC_KIND_CNNPY).  Neither contains a Dropout layer, so the training forward is the inference
+ * forward.  MDC_KIND_VTCNN2 is refused (MDC_ENOTSUP): its training exists only in the vendored DeepSig notebook.  f32.
+ *
+ *     model.compile(loss='categorical_crossentropy', optimizer='adam')     cnn.py:113     mdc_trainer_create (+ _set_adam)
+ *     (the freshly initialised / loaded weights)                            cnn.py:108-111 mdc_trainer_set_tensor(MDC_TRAIN_WEIGHTS)
+ *     model.fit(...): one mini-batch of one epoch                           cnn.py:135     mdc_train_batch
+ *     ... validation_data=(X_test, Y_test): val_loss after each epoch       cnn.py:140     mdc_trainer_evaluate + mdc_trainer_read
+ *     ModelCheckpoint(filepath, save_best_only=True) / load_weights         cnn.py:143-147 mdc_trainer_get_tensor (weights, Adam m / v,
+ *                                                                                          iterations: all a Keras full-model .h5 holds)
+ * The loss is Keras 2.4's categorical_crossentropy on the softmax OUTPUT (the model ends in Activation('softmax') +
+ * Reshape, so the loss sees probabilities): q = p / sum(p), clipped to [1e-7, 1 - 1e-7], L = -sum_c y_c log q_c, mean over
+ * the batch; the clip passes no gradient outside its interval, a ReLU none where its input is <= 0.  The optimizer is
+ * TensorFlow 2.4's Adam: alpha = lr sqrt(1 - beta2^t) / (1 - beta1^t), m += (g - m)(1 - beta1), v += (g g - v)(1 - beta2),
+ * w -= m alpha / (sqrt(v) + eps) with t = iterations + 1 (eps is NOT scaled by the bias correction).
+ * Everything below runs on the trainer's device; x_dev (frames (., 2, 128) f32, 16-byte aligned) and y_dev (target rows
+ * (., classes) f32: the one-hot rows of cnn.py:74-82, or any distribution) are the caller's buffers holding the WHOLE set;
+ * a mini-batch is the frames order_dev[first .. first + count) of it (order_dev: int32 indices on the device, the
+ * epoch's shuffle -- frames are never moved; NULL = the identity).  mdc_train_batch and mdc_trainer_evaluate only enqueue
+ * on hip_stream (two launches, no synchronisation, no allocation: capturable in a hipGraph; Adam's step count lives on the
+ * device).  A step is reproducible bit for bit (fixed-order reductions, no float atomics).  One stream at a time per trainer. */
+typedef struct mdc_trainer mdc_trainer;   /* opaque: f32 master weights in the Keras layouts, Adam state, scratch */
+
+MDC_API int mdc_trainer_create(const mdc_topology* topo, int device, mdc_trainer** out);
+MDC_API int mdc_trainer_num_layers(const mdc_trainer* t);
+MDC_API int mdc_trainer_layer_sizes(const mdc_trainer* t, int layer, size_t* kernel_elems, size_t* bias_elems);
+
+/* keras.optimizers.Adam(lr, beta_1, beta_2, epsilon); the defaults (1e-3, 0.9, 0.999, 1e-7 -- what 'adam' at cnn.py:113
+ * means and what every bundled .h5's training_config records) hold until this is called. */
+MDC_API int mdc_trainer_set_adam(mdc_trainer* t, float lr, float beta1, float beta2, float eps);
+
+/* Per-layer tensors in the layouts of mdc_set_weights.  MDC_TRAIN_WEIGHTS must be set for every layer before the first
+ * batch; Adam's moments start at zero and `iterations` at 0 (set them to resume from a full-model .h5, whose
+ * /optimizer_weights group holds exactly these).  MDC_TRAIN_GRADIENT (get only): d(mean loss)/d(weights) of the last
+ * mdc_train_batch.  Both calls synchronise hip_stream (the host buffers are complete / reusable on return). */
+enum { MDC_TRAIN_WEIGHTS = 0, MDC_TRAIN_ADAM_M = 1, MDC_TRAIN_ADAM_V = 2, MDC_TRAIN_GRADIENT = 3 };
+MDC_API int mdc_trainer_set_tensor(mdc_trainer* t, int which, int layer, const float* kernel_host, size_t kernel_elems,
+                           const float* bias_host, size_t bias_elems, void* hip_stream);
+MDC_API int mdc_trainer_get_tensor(mdc_trainer* t, int which, int layer, float* kernel_host, size_t kernel_elems,
+                           float* bias_host, size_t bias_elems, void* hip_stream);
+MDC_API int mdc_trainer_set_iterations(mdc_trainer* t, int64_t iterations, void* hip_stream);
+
+/* model.train_on_batch / one step of model.fit (cnn.py:135): forward, loss, backward over the `count` frames and, if
+ * `apply` != 0, one Adam update (apply = 0: the gradient is computed and kept for MDC_TRAIN_GRADIENT, nothing changes).
+ * The batch's summed loss and frame count are added to the trainer's running training statistics. */
+MDC_API int mdc_train_batch(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first,
+                    int64_t count, int apply, void* hip_stream);
+
+/* The val_loss half of model.fit's epoch end / model.evaluate with the weights as they are now (cnn.py:140, 153): adds the
+ * summed per-sample loss and the frame count to the trainer's evaluation statistics. */
+MDC_API int mdc_trainer_evaluate(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first,
+                         int64_t count, void* hip_stream);
+
+/* Synchronise hip_stream and read the statistics (each pointer may be NULL): sums of per-sample losses and frame counts
+ * since the last reset, for training batches and for evaluation (mean = sum / frames: fit's `loss` and `val_loss`), and
+ * Adam's step count.  reset != 0 zeroes the four statistics (not `iterations`). */
+MDC_API int mdc_trainer_read(mdc_trainer* t, int reset, double* train_loss_sum, int64_t* train_frames, double* eval_loss_sum,
+                     int64_t* eval_frames, int64_t* iterations, void* hip_stream);
+
+MDC_API void mdc_trainer_destroy(mdc_trainer* t);
+
+MDC_API const char* mdc_last_error(void);
+MDC_API void mdc_destroy(mdc_model* m);
 
 #ifdef __cplusplus
 }

@@ -26,8 +26,12 @@ EXPORTS = [
     "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax",
     "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8",
     "mdc_crossentropy",
+    "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_tensor",
+    "mdc_trainer_get_tensor", "mdc_trainer_set_iterations", "mdc_train_batch", "mdc_trainer_evaluate", "mdc_trainer_read",
+    "mdc_trainer_destroy",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
+TRAIN_WEIGHTS, TRAIN_ADAM_M, TRAIN_ADAM_V, TRAIN_GRADIENT = 0, 1, 2, 3
 MDC_OPT_FP8_BF16_FEATURES = 1      # include/mdc.h: option bit in mdc_topology.reserved[0]
 HOP_FRAME = 128
 
@@ -85,10 +89,25 @@ def lib(variant: str = "product") -> C.CDLL:
     L.mdc_predict_host.argtypes = [vp, vp, i64, vp, vp, i64]
     L.mdc_predict_host_iq_u8.argtypes = [vp, vp, i64, i64, C.c_float, vp, vp, i64]
     L.mdc_crossentropy.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    fp = C.POINTER(C.c_float)
+    L.mdc_trainer_create.argtypes = [C.POINTER(MdcTopology), i32, C.POINTER(vp)]
+    L.mdc_trainer_num_layers.argtypes = [vp]
+    L.mdc_trainer_layer_sizes.argtypes = [vp, i32, C.POINTER(sz), C.POINTER(sz)]
+    L.mdc_trainer_set_adam.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.mdc_trainer_set_tensor.argtypes = [vp, i32, i32, fp, sz, fp, sz, vp]
+    L.mdc_trainer_get_tensor.argtypes = [vp, i32, i32, fp, sz, fp, sz, vp]
+    L.mdc_trainer_set_iterations.argtypes = [vp, i64, vp]
+    L.mdc_train_batch.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp]
+    L.mdc_trainer_evaluate.argtypes = [vp, vp, vp, vp, i64, i64, vp]
+    L.mdc_trainer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64), vp]
+    L.mdc_trainer_destroy.argtypes = [vp]
+    L.mdc_trainer_destroy.restype = None
     for name in ("mdc_create", "mdc_num_layers", "mdc_layer_sizes", "mdc_set_weights", "mdc_finalize",
                  "mdc_forward", "mdc_set_profiling", "mdc_profile_slots", "mdc_profile_read", "mdc_profile_reset",
                  "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax", "mdc_forward_iq_u8",
-                 "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8", "mdc_crossentropy"):
+                 "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8", "mdc_crossentropy",
+                 "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_tensor",
+                 "mdc_trainer_get_tensor", "mdc_trainer_set_iterations", "mdc_train_batch", "mdc_trainer_evaluate", "mdc_trainer_read"):
         getattr(L, name).restype = i32
     if L.mdc_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{os.path.basename(path)} ABI version {L.mdc_abi_version()} != {ABI_VERSION}; rebuild it")

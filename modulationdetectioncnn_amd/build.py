@@ -21,6 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libmdc.so")
 ARCH = "gfx950"
+VERSION_SCRIPT = os.path.join(CSRC, "libmdc.map")
 # Two libraries come out of the same sources:
 #   "product"     libmdc.so      one kernel per role; nothing under mdc_forward* reads the environment
 #   "alternates"  libmdc_alt.so  -DMDC_ALTERNATES: additionally the measured-slower alternate kernels that the GPU suite
@@ -31,7 +32,9 @@ VARIANTS = {"product": (OBJ, LIB, ()),
             "alternates": (os.path.join(HERE, "csrc", "build_alt"), os.path.join(HERE, "libmdc_alt.so"), ("-DMDC_ALTERNATES",))}
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"),
-            "-I", CSRC, "-Wall", "-Wno-unused-function", "-pthread"]
+            "-I", CSRC, "-Wall", "-Wno-unused-function", "-pthread",
+            # only the MDC_API entry points of include/mdc.h are dynamic symbols (tests/test_cabi.py: nm -D == the header)
+            "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 # (no -fno-exceptions: the C ABI catches std::bad_alloc & co. at the boundary and returns MDC_ENOMEM, mdc_api.hip)
 
 
@@ -97,8 +100,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: s
             list(ex.map(cc, jobs))
     with open(stamp, "w") as f:
         f.write(key + "\n")
-    if jobs or not _newer(lib_path, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", lib_path, *objs]
+    if jobs or not _newer(lib_path, objs + [VERSION_SCRIPT]):
+        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", f"-Wl,--version-script={VERSION_SCRIPT}", "-o", lib_path, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

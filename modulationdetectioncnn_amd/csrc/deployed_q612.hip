@@ -60,8 +60,11 @@ __device__ __forceinline__ int quant(float v) {                  // float2fix: t
 // the position-0 weights [h][f][c], then the per-lane tables [slot][lane]; dense (n,C) / labels (n): each may be NULL
 struct QParams { const void* x; int x_is_q; long n; const int* tab; int* dense; int* labels; };
 
+// Occupancy: the 3-filter kernel fits two waves per SIMD (104 VGPRs); the 10-filter one keeps 120 weight registers per lane
+// and under a 256-register budget spilled 22 of them to scratch (84 B per lane, round 4) -- it gets the whole register
+// file (one wave per SIMD, no scratch; A/B in profiles/r05_q612_occupancy_ab.log).
 template <int F>
-__global__ __launch_bounds__(256, 2) void deployed_q612_kernel(const void* __restrict__ px, int x_is_q, long pn, const int* __restrict__ ptab,
+__global__ __launch_bounds__(256, F == 10 ? 1 : 2) void deployed_q612_kernel(const void* __restrict__ px, int x_is_q, long pn, const int* __restrict__ ptab,
                                                                int* __restrict__ pdense, int* __restrict__ plabels) {
     const QParams p{px, x_is_q, pn, ptab, pdense, plabels};
     constexpr int kW0 = 64;                          // position-0 weights [h][f][c]

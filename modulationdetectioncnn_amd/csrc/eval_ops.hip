@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void crossentropy_kernel(const float* __restri
         float sum = 0.f;
         for (int c = 0; c < C; ++c) sum += row[c];
         float p = row[t] / sum;
-        p = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+        // a NaN row (Inf / NaN samples in, or a row summing to 0) stays NaN, as Keras' clip_by_value leaves it (fmaxf alone
+        // would turn it into 1e-7 and the score into a finite number)
+        if (p == p) p = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
         acc -= (double)logf(p);
     }
     part[threadIdx.x] = acc;

@@ -56,24 +56,6 @@ ProfScope::~ProfScope() {
 
 using namespace mdc;
 
-// Nothing throws across the boundary: the library is built WITH exceptions so that an allocation failure inside
-// (std::vector growth in the packers, event lists) surfaces as MDC_ENOMEM instead of aborting the host process.
-template <class Fn>
-static int guarded(const char* what, Fn&& fn) noexcept {
-    try {
-        return fn();
-    } catch (const std::bad_alloc&) {
-        set_error("%s: out of host memory", what);
-        return MDC_ENOMEM;
-    } catch (const std::exception& e) {
-        set_error("%s: %s", what, e.what());
-        return MDC_EIO;
-    } catch (...) {
-        set_error("%s: unexpected exception", what);
-        return MDC_EIO;
-    }
-}
-
 static int layer_layout(mdc_model* m) {
     const mdc_topology& t = m->topo;
     switch (t.kind) {

@@ -4,7 +4,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -13,6 +15,24 @@
 namespace mdc {
 
 void set_error(const char* fmt, ...);
+
+// Nothing throws across the boundary: the library is built WITH exceptions so that an allocation failure inside
+// (std::vector growth in the packers, event lists) surfaces as MDC_ENOMEM instead of aborting the host process.
+template <class Fn>
+inline int guarded(const char* what, Fn&& fn) noexcept {
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory", what);
+        return MDC_ENOMEM;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", what, e.what());
+        return MDC_EIO;
+    } catch (...) {
+        set_error("%s: unexpected exception", what);
+        return MDC_EIO;
+    }
+}
 
 #define MDC_HIP(call)                                                                      \
     do {                                                                                   \

@@ -1,0 +1,679 @@
+// Training step of the two nets the reference trains (/root/reference citations):
+//     model.compile(loss='categorical_crossentropy', optimizer='adam')                       cnn.py:113, CNN.ipynb cell 6
+//     model.fit(X_train, Y_train, batch_size=1024, epochs=100, validation_data=..., callbacks=[ModelCheckpoint,
+//               EarlyStopping])                                                              cnn.py:122-147, CNN.ipynb cell 8
+// for MDC_KIND_DEPLOYED (CNN.ipynb cell 6: T1 F=3 / T2 F=10) and MDC_KIND_CNNPY (cnn.py:104-112: T4), in f32.  Neither net
+// has a Dropout layer (`dr` is never used in them), so the training forward IS the inference forward.  The canonical
+// VT-CNN2 (T3) is trained only in the vendored DeepSig notebook: out of scope.
+//
+// One mini-batch = two launches on the caller's stream, no host synchronisation, nothing allocated:
+//   mdc_train_grad   one wave per slice of the batch (frames g, g+G, ...): forward, Keras' categorical cross-entropy on
+//                    the softmax rows (row / sum, clip to [1e-7, 1-1e-7], -sum y log q; the clip blocks the gradient
+//                    outside the interval, the ReLUs where the pre-activation is <= 0), backward with the activations
+//                    RECOMPUTED from the frame still in registers -- nothing but the 1 KiB frame is read per sample and
+//                    nothing per-sample is written.  A lane owns a fixed set of weights (deployed: 4 (+1) conv
+//                    positions x F filters x 3 classes of the dense kernel; cnn.py: 2 of the 128 input channels x 2 taps x
+//                    F filters of the conv kernel) for the whole slice, so their gradients accumulate in its registers and
+//                    only the per-frame reductions (3 class sums / 3F conv sums) cross lanes (xor butterfly: every lane
+//                    ends with the same bits).  Each wave writes ONE partial gradient vector; the shuffle of fit() is an
+//                    index array (`order`), frames are never moved.
+//   mdc_train_adam   sums the G partials in a fixed order (the result depends on (count, G) only -- no float atomics, so
+//                    a step is reproducible bit for bit), scales by 1/count (gradient of the MEAN loss), and applies
+//                    TensorFlow 2.4's Adam: alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1); v += (g*g-v)(1-b2);
+//                    w -= m*alpha/(sqrt(v)+eps).  t lives on the device (incremented by the gradient kernel), so a
+//                    captured hipGraph of an epoch replays correctly.
+// The batch of the reference (1,024 frames x 2,334 parameters) is launch-latency bound on this chip; that is why a step
+// is two launches and an epoch needs no host round trip but the final read of the loss.
+#include "mdc_internal.h"
+
+#include <cstddef>
+#include <cstring>
+#include <new>
+
+struct mdc_trainer {
+    mdc_topology topo{};
+    int device = 0;
+    int nlayers = 0;
+    size_t nk[4]{}, nb[4]{};
+    size_t off_k[4]{}, off_b[4]{};      // offsets into the flat parameter vector (Keras layouts, layer by layer: kernel, bias)
+    size_t P = 0;
+    bool have[4]{};
+    float lr = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f;      // keras.optimizers.Adam() defaults = the .h5 files' training_config
+    // device state
+    float* d_params = nullptr;   // [P] master weights
+    float* d_m = nullptr;        // [P] Adam first moment
+    float* d_v = nullptr;        // [P] Adam second moment
+    float* d_grad = nullptr;     // [P] gradient of the last batch's mean loss
+    float* d_partials = nullptr; // [kMaxWaves][P]
+    double* d_loss_partials = nullptr;   // [kMaxWaves]
+    void* d_state = nullptr;     // TrainState
+};
+
+namespace mdc {
+
+namespace {
+
+constexpr int kMaxWaves = 1024;      // partial gradient vectors per batch
+constexpr float kKerasEps = 1e-7f;   // K.epsilon()
+
+struct TrainState {
+    long long iterations;      // Adam's `iter` (optimizer_weights/Adam/iter:0 of the .h5)
+    long long train_frames;
+    double train_loss;         // sum over frames of the per-sample loss since the last read (fit's running epoch loss)
+    long long eval_frames;
+    double eval_loss;
+};
+
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// softmax -> Keras categorical_crossentropy on the probabilities -> gradient w.r.t. the softmax INPUT.  y: the target row.
+template <int CMAX>
+__device__ __forceinline__ float softmax_xent(const float (&d)[CMAX], const float (&y)[CMAX], int C, float (&gd)[CMAX]) {
+    float mx = d[0];
+#pragma unroll
+    for (int c = 1; c < CMAX; ++c) if (c < C) mx = fmaxf(mx, d[c]);
+    float p[CMAX], se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { p[c] = c < C ? expf(d[c] - mx) : 0.f; se += p[c]; }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { p[c] = p[c] / se; s += p[c]; }
+    float li = 0.f, sg = 0.f, gq[CMAX], q[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        q[c] = p[c] / s;
+        const float qc = fminf(fmaxf(q[c], kKerasEps), 1.f - kKerasEps);
+        const bool in = c < C && q[c] >= kKerasEps && q[c] <= 1.f - kKerasEps;
+        if (c < C && y[c] != 0.f) li -= y[c] * logf(qc);
+        gq[c] = in ? -y[c] / qc : 0.f;
+        sg += gq[c] * q[c];
+    }
+    float sp = 0.f, gp[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { gp[c] = (gq[c] - sg) / s; sp += gp[c] * p[c]; }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) gd[c] = p[c] * (gp[c] - sp);
+    return li;
+}
+
+// ---- deployed net (CNN.ipynb cell 6): lane = (row h = lane>>5, positions w = 4l'..4l'+3, l' = lane&31; lane l' = 31 also w = 128)
+// WLDS: the lane's 5 x F x 3 dense weights live in LDS ([entry][lane]: conflict-free) instead of registers -- the gradient
+// kernel of the 10-filter net would otherwise hold 150 weights + 150 gradient sums per lane and spill.
+template <int F, bool GRAD, bool WLDS>
+__global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const int* __restrict__ order, long first, int count,
+                                                           const float* __restrict__ params, float* __restrict__ partials,
+                                                           double* __restrict__ loss_partials, TrainState* __restrict__ st, int bump_iter) {
+    constexpr int C = 3, S = 5;
+    constexpr int offCb = 2 * F, offWd = 3 * F, offBd = 3 * F + 258 * F * C, P = offBd + C;
+    __shared__ float sW[WLDS ? S * F * C * 64 : 1];
+    const int lane = threadIdx.x, h = lane >> 5, lp = lane & 31;
+    const int G = gridDim.x, g = blockIdx.x;
+    float k0[F], k1[F], cb[F], bd[C];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { k0[f] = params[f]; k1[f] = params[F + f]; cb[f] = params[offCb + f]; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) bd[c] = params[offBd + c];
+    // dense kernel row of (h, w, f): h*129F + w*F + f   (channels_last Flatten)
+    float Wr[WLDS ? 1 : S][WLDS ? 1 : F][WLDS ? 1 : C], dW[GRAD ? S : 1][GRAD ? F : 1][GRAD ? C : 1];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int w = s < 4 ? 4 * lp + s : 128;
+        const bool mine = s < 4 || lp == 31;
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float v = mine ? params[offWd + ((h * 129 + w) * F + f) * C + c] : 0.f;
+                if (WLDS) sW[((s * F + f) * C + c) * 64 + lane] = v;      // (read back by this lane only: no barrier needed)
+                else Wr[s][f][c] = v;
+                if (GRAD) dW[s][f][c] = 0.f;
+            }
+    }
+    auto Wv = [&](int s, int f, int c) -> float { return WLDS ? sW[((s * F + f) * C + c) * 64 + lane] : Wr[WLDS ? 0 : s][WLDS ? 0 : f][WLDS ? 0 : c]; };
+    float gk0[F], gk1[F], gcb[F], gbd[C];
+#pragma unroll
+    for (int f = 0; f < F; ++f) gk0[f] = gk1[f] = gcb[f] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gbd[c] = 0.f;
+    double loss = 0.0;
+
+    for (int i = g; i < count; i += G) {
+        if (WLDS) asm volatile("" ::: "memory");      // keep the LDS weight reads inside the loop (hoisted, they are 150 registers again)
+        const long idx = order ? (long)order[first + i] : first + i;
+        const float4 xv = *reinterpret_cast<const float4*>(x + idx * kFrameFloats + h * kSamples + 4 * lp);
+        float xprev = __shfl_up(xv.w, 1, 64);
+        if (lp == 0) xprev = 0.f;                                       // ZeroPadding2D((0,1)): x[h][-1] = 0
+        const float xin[S] = {xprev, xv.x, xv.y, xv.z, xv.w};           // x[h][w-1]
+        const float xcu[S] = {xv.x, xv.y, xv.z, xv.w, 0.f};             // x[h][w]   (x[h][128] = 0)
+        float yv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) yv[c] = y[idx * C + c];
+        float z[C] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float a = fmaxf(fmaf(k1[f], xcu[s], k0[f] * xin[s]) + cb[f], 0.f);
+#pragma unroll
+                for (int c = 0; c < C; ++c) z[c] = fmaf(a, Wv(s, f, c), z[c]);
+            }
+        float d[C], gz[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { z[c] = wave_allsum(z[c]) + bd[c]; d[c] = fmaxf(z[c], 0.f); }      // Dense(3, activation='relu')
+        loss += (double)softmax_xent<C>(d, yv, C, gz);
+        if (GRAD) {
+            if (WLDS) asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < C; ++c) { gz[c] = z[c] > 0.f ? gz[c] : 0.f; gbd[c] += gz[c]; }
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float pre = fmaf(k1[f], xcu[s], k0[f] * xin[s]) + cb[f];
+                    const float a = fmaxf(pre, 0.f);
+                    float da = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { da = fmaf(Wv(s, f, c), gz[c], da); dW[s][f][c] = fmaf(a, gz[c], dW[s][f][c]); }
+                    const float dpre = pre > 0.f ? da : 0.f;            // (W = 0 in the slots a lane does not own: da = 0 there)
+                    gk0[f] = fmaf(dpre, xin[s], gk0[f]);
+                    gk1[f] = fmaf(dpre, xcu[s], gk1[f]);
+                    gcb[f] += dpre;
+                }
+        }
+    }
+    if (lane == 0) loss_partials[g] = loss;
+    if (!GRAD) return;
+    float* out = partials + (size_t)g * P;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int w = s < 4 ? 4 * lp + s : 128;
+        if (s < 4 || lp == 31)
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int c = 0; c < C; ++c) out[offWd + ((h * 129 + w) * F + f) * C + c] = dW[GRAD ? s : 0][GRAD ? f : 0][GRAD ? c : 0];
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const float a = wave_allsum(gk0[f]), b = wave_allsum(gk1[f]), c = wave_allsum(gcb[f]);
+        if (lane == 0) { out[f] = a; out[F + f] = b; out[offCb + f] = c; }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[offBd + c] = gbd[c];
+        if (bump_iter && g == 0) st->iterations += 1;      // the Adam launch behind this one on the stream reads t = iterations
+    }
+}
+
+// ---- cnn.py's literal net (cnn.py:104-112 as TensorFlow builds it: H=1, W=2, C=128): lane owns input channels lane, lane+64
+constexpr int kTF = 10, kTD = 16, kTC = 16;      // bounds of MDC_KIND_CNNPY (mdc_create): filters <= 10, hidden <= 16, classes <= 16
+
+template <bool GRAD>
+__global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ order,
+                                                        long first, int count, int F, int D, int C, const float* __restrict__ params,
+                                                        float* __restrict__ partials, double* __restrict__ loss_partials,
+                                                        TrainState* __restrict__ st, int bump_iter) {
+    const int A = 3 * F;
+    const int offCb = 256 * F, offW1 = offCb + F, offB1 = offW1 + A * D, offW2 = offB1 + D, offB2 = offW2 + D * C, P = offB2 + C;
+    __shared__ float sW1[3 * kTF * kTD], sW2[kTD * kTC], sB1[kTD], sB2[kTC], sCb[kTF];
+    __shared__ float sA[3 * kTF], sPre[3 * kTF], sH[kTD], sZ1[kTD], sLg[kTC], sGlg[kTC], sGz1[kTD], sGa[3 * kTF];
+    const int lane = threadIdx.x, G = gridDim.x, g = blockIdx.x;
+    for (int i = lane; i < A * D; i += 64) sW1[i] = params[offW1 + i];
+    for (int i = lane; i < D * C; i += 64) sW2[i] = params[offW2 + i];
+    if (lane < D) sB1[lane] = params[offB1 + lane];
+    if (lane < C) sB2[lane] = params[offB2 + lane];
+    if (lane < F) sCb[lane] = params[offCb + lane];
+    // conv kernel HWIO (1,2,128,F): ((kw*128 + c)*F + f)
+    float K[2][2][kTF], gK[2][2][kTF];      // [channel slot][kw][f]
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+            for (int f = 0; f < kTF; ++f) {
+                K[u][kw][f] = f < F ? params[(kw * 128 + lane + 64 * u) * F + f] : 0.f;
+                gK[u][kw][f] = 0.f;
+            }
+    float gW1[8], gW2[4], gB1 = 0.f, gB2 = 0.f, gCb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gW1[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gW2[i] = 0.f;
+    double loss = 0.0;
+    __syncthreads();
+
+    for (int i = g; i < count; i += G) {
+        const long idx = order ? (long)order[first + i] : first + i;
+        const float* fr = x + idx * kFrameFloats;
+        const float xi[2] = {fr[lane], fr[lane + 64]}, xq[2] = {fr[kSamples + lane], fr[kSamples + lane + 64]};
+        // padded width 4: [0, I, Q, 0]; conv output w: K[kw=0] . xp[w] + K[kw=1] . xp[w+1]
+        float pre[3][kTF];
+#pragma unroll
+        for (int f = 0; f < kTF; ++f) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p0 = fmaf(K[u][1][f], xi[u], p0);
+                p1 = fmaf(K[u][0][f], xi[u], fmaf(K[u][1][f], xq[u], p1));
+                p2 = fmaf(K[u][0][f], xq[u], p2);
+            }
+            if (f < F) {      // (uniform)
+                pre[0][f] = wave_allsum(p0) + sCb[f];
+                pre[1][f] = wave_allsum(p1) + sCb[f];
+                pre[2][f] = wave_allsum(p2) + sCb[f];
+            } else {
+                pre[0][f] = pre[1][f] = pre[2][f] = 0.f;
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int f = 0; f < kTF; ++f)
+                    if (f < F) { sPre[w * F + f] = pre[w][f]; sA[w * F + f] = fmaxf(pre[w][f], 0.f); }
+        }
+        __syncthreads();
+        if (lane < D) {      // Dense(D, relu)
+            float z = sB1[lane];
+            for (int j = 0; j < A; ++j) z = fmaf(sA[j], sW1[j * D + lane], z);
+            sZ1[lane] = z;
+            sH[lane] = fmaxf(z, 0.f);
+        }
+        __syncthreads();
+        if (lane < C) {      // Dense(C)
+            float z = sB2[lane];
+            for (int d = 0; d < D; ++d) z = fmaf(sH[d], sW2[d * C + lane], z);
+            sLg[lane] = z;
+        }
+        __syncthreads();
+        float lg[kTC], yv[kTC], glg[kTC];
+#pragma unroll
+        for (int c = 0; c < kTC; ++c) { lg[c] = c < C ? sLg[c] : 0.f; yv[c] = c < C ? y[idx * C + c] : 0.f; }
+        loss += (double)softmax_xent<kTC>(lg, yv, C, glg);
+        if (GRAD) {
+            if (lane < C) {
+#pragma unroll
+                for (int c = 0; c < kTC; ++c) if (c == lane) { sGlg[c] = glg[c]; gB2 += glg[c]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {      // dW2[d][c] = h[d] * glg[c], entry e = lane + 64u
+                const int e = lane + 64 * u;
+                if (e < D * C) gW2[u] = fmaf(sH[e / C], sGlg[e % C], gW2[u]);
+            }
+            if (lane < D) {
+                float gh = 0.f;
+                for (int c = 0; c < C; ++c) gh = fmaf(sW2[lane * C + c], sGlg[c], gh);
+                const float gz = sZ1[lane] > 0.f ? gh : 0.f;
+                sGz1[lane] = gz;
+                gB1 += gz;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {      // dW1[j][d] = a[j] * gz1[d]
+                const int e = lane + 64 * u;
+                if (e < A * D) gW1[u] = fmaf(sA[e / D], sGz1[e % D], gW1[u]);
+            }
+            if (lane < A) {
+                float ga = 0.f;
+                for (int d = 0; d < D; ++d) ga = fmaf(sW1[lane * D + d], sGz1[d], ga);
+                sGa[lane] = sPre[lane] > 0.f ? ga : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < kTF; ++f)
+                if (f < F) {
+                    const float g0 = sGa[f], g1 = sGa[F + f], g2 = sGa[2 * F + f];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        gK[u][1][f] = fmaf(g0, xi[u], fmaf(g1, xq[u], gK[u][1][f]));
+                        gK[u][0][f] = fmaf(g1, xi[u], fmaf(g2, xq[u], gK[u][0][f]));
+                    }
+                    if (lane == f) gCb += g0 + g1 + g2;
+                }
+        }
+        __syncthreads();      // the s* vectors are rewritten by the next frame
+    }
+    if (lane == 0) loss_partials[g] = loss;
+    if (!GRAD) return;
+    float* out = partials + (size_t)g * P;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+            for (int f = 0; f < kTF; ++f)
+                if (f < F) out[(kw * 128 + lane + 64 * u) * F + f] = gK[u][kw][f];
+    if (lane < F) out[offCb + lane] = gCb;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int e = lane + 64 * u; if (e < A * D) out[offW1 + e] = gW1[u]; }
+    if (lane < D) out[offB1 + lane] = gB1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u; if (e < D * C) out[offW2 + e] = gW2[u]; }
+    if (lane < C) out[offB2 + lane] = gB2;
+    if (lane == 0 && bump_iter && g == 0) st->iterations += 1;
+}
+
+// ---- fixed-order reduction of the partials + TensorFlow 2.4's Adam.  Block = 64 parameters x 4 slices of the G partials.
+// mode: 0 = losses only (evaluation), 1 = gradient stored, 2 = gradient stored and applied
+__global__ __launch_bounds__(256) void train_adam_kernel(const float* __restrict__ partials, const double* __restrict__ loss_partials, int G,
+                                                        int P, int count, int mode, float lr, float beta1, float beta2, float eps,
+                                                        float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
+                                                        float* __restrict__ grad, TrainState* __restrict__ st) {
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    if (mode != 0) {
+        float acc = 0.f;
+        if (i < P) {
+            const int per = (G + 3) / 4, lo = slice * per, hi = min(G, lo + per);
+            for (int w = lo; w < hi; ++w) acc += partials[(size_t)w * P + i];
+        }
+        part[slice][col] = acc;
+        __syncthreads();
+        if (slice == 0 && i < P) {
+            const float gsum = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+            const float gmean = gsum / (float)count;
+            grad[i] = gmean;
+            if (mode == 2) {
+                const float t = (float)st->iterations;      // already incremented by the gradient launch
+                const float alpha = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
+                const float mi = m[i] + (gmean - m[i]) * (1.f - beta1);
+                const float vi = v[i] + (gmean * gmean - v[i]) * (1.f - beta2);
+                m[i] = mi;
+                v[i] = vi;
+                params[i] -= (mi * alpha) / (sqrtf(vi) + eps);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < G; ++w) s += loss_partials[w];
+        if (mode == 0) { st->eval_loss += s; st->eval_frames += count; }
+        else { st->train_loss += s; st->train_frames += count; }
+    }
+}
+
+int trainer_layout(mdc_trainer* t) {
+    const mdc_topology& tp = t->topo;
+    if (tp.kind == MDC_KIND_DEPLOYED) {
+        if (tp.filters != 3 && tp.filters != 10) { set_error("trainer: deployed filters must be 3 or 10 (got %d)", tp.filters); return MDC_ENOTSUP; }
+        if (tp.classes != 3) { set_error("trainer: deployed classes must be 3 (got %d)", tp.classes); return MDC_ENOTSUP; }
+        t->nlayers = 2;
+        t->nk[0] = 2 * (size_t)tp.filters;                  t->nb[0] = tp.filters;
+        t->nk[1] = 258 * (size_t)tp.filters * tp.classes;   t->nb[1] = tp.classes;
+    } else if (tp.kind == MDC_KIND_CNNPY) {
+        if (tp.filters < 1 || tp.filters > kTF || tp.hidden < 1 || tp.hidden > kTD || tp.classes < 2 || tp.classes > kTC) {
+            set_error("trainer: cnnpy needs filters 1..%d, hidden 1..%d, classes 2..%d (got %d,%d,%d)", kTF, kTD, kTC, tp.filters, tp.hidden, tp.classes);
+            return MDC_ENOTSUP;
+        }
+        t->nlayers = 3;
+        t->nk[0] = 2 * 128 * (size_t)tp.filters;            t->nb[0] = tp.filters;
+        t->nk[1] = 3 * (size_t)tp.filters * tp.hidden;      t->nb[1] = tp.hidden;
+        t->nk[2] = (size_t)tp.hidden * tp.classes;          t->nb[2] = tp.classes;
+    } else {
+        set_error("trainer: the reference trains MDC_KIND_DEPLOYED (CNN.ipynb cell 6) and MDC_KIND_CNNPY (cnn.py:104-112) only");
+        return MDC_ENOTSUP;
+    }
+    size_t off = 0;
+    for (int l = 0; l < t->nlayers; ++l) {
+        t->off_k[l] = off; off += t->nk[l];
+        t->off_b[l] = off; off += t->nb[l];
+    }
+    t->P = off;
+    return MDC_OK;
+}
+
+int waves_for(int64_t count, bool grad) {
+    // a wave per 4 frames while the batch is small (1,024 frames -> 256 waves, one per CU); evaluation of a large set
+    // wants the memory system busy instead: up to kMaxWaves either way
+    int64_t g = (count + 3) / 4;
+    if (g < 1) g = 1;
+    if (g > kMaxWaves) g = kMaxWaves;
+    (void)grad;
+    return (int)g;
+}
+
+int launch_batch(mdc_trainer* t, const float* x, const float* y, const int32_t* order, int64_t first, int64_t count, int mode, hipStream_t s) {
+    const int G = waves_for(count, mode != 0);
+    auto* st = static_cast<TrainState*>(t->d_state);
+    const int bump = mode == 2 ? 1 : 0;
+    const int cnt = (int)count;
+    if (t->topo.kind == MDC_KIND_DEPLOYED) {
+        if (t->topo.filters == 3) {
+            if (mode) hipLaunchKernelGGL((train_deployed_kernel<3, true, false>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+            else      hipLaunchKernelGGL((train_deployed_kernel<3, false, false>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+        } else {
+            if (mode) hipLaunchKernelGGL((train_deployed_kernel<10, true, true>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+            else      hipLaunchKernelGGL((train_deployed_kernel<10, false, false>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+        }
+    } else {
+        if (mode) hipLaunchKernelGGL(train_cnnpy_kernel<true>, dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->topo.filters, t->topo.hidden, t->topo.classes,
+                                     t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+        else      hipLaunchKernelGGL(train_cnnpy_kernel<false>, dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->topo.filters, t->topo.hidden, t->topo.classes,
+                                     t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+    }
+    MDC_HIP(hipGetLastError());
+    const int P = (int)t->P;
+    const int blocks = mode == 0 ? 1 : (P + 63) / 64;
+    hipLaunchKernelGGL(train_adam_kernel, dim3(blocks), dim3(256), 0, s, t->d_partials, t->d_loss_partials, G, P, cnt, mode, t->lr, t->beta1, t->beta2,
+                       t->eps, t->d_params, t->d_m, t->d_v, t->d_grad, st);
+    MDC_HIP(hipGetLastError());
+    return MDC_OK;
+}
+
+int check_batch_args(const char* what, mdc_trainer* t, const float* x, const float* y, int64_t first, int64_t count) {
+    if (!t) { set_error("%s: null trainer", what); return MDC_EINVAL; }
+    for (int l = 0; l < t->nlayers; ++l)
+        if (!t->have[l]) { set_error("%s: layer %d has no weights (mdc_trainer_set_weights)", what, l); return MDC_ESTATE; }
+    if (first < 0 || count < 0) { set_error("%s: negative range", what); return MDC_EINVAL; }
+    if (count > (int64_t)1 << 30) { set_error("%s: at most 2^30 frames per call", what); return MDC_EINVAL; }
+    if (count > 0 && (!x || !y)) { set_error("%s: null frames or targets", what); return MDC_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) { set_error("%s: frames must be 16-byte aligned", what); return MDC_EINVAL; }
+    return MDC_OK;
+}
+
+}  // namespace
+
+}  // namespace mdc
+
+using namespace mdc;
+
+extern "C" {
+
+int mdc_trainer_create(const mdc_topology* topo, int device, mdc_trainer** out) {
+    return guarded("mdc_trainer_create", [&]() -> int {
+        if (!topo || !out) { set_error("mdc_trainer_create: null argument"); return MDC_EINVAL; }
+        *out = nullptr;
+        for (int i = 0; i < 4; ++i) if (topo->reserved[i] != 0) { set_error("mdc_trainer_create: reserved[] must be 0"); return MDC_EINVAL; }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MDC_ENODEV; }
+        if (device < 0 || device >= ndev) { set_error("device %d out of range (have %d)", device, ndev); return MDC_ENODEV; }
+        hipDeviceProp_t prop;
+        MDC_HIP(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            set_error("device %d is %s; libmdc.so carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+            return MDC_ENODEV;
+        }
+        mdc_trainer* t = new (std::nothrow) mdc_trainer();
+        if (!t) { set_error("out of host memory"); return MDC_ENOMEM; }
+        t->topo = *topo;
+        t->device = device;
+        int rc = trainer_layout(t);
+        if (rc != MDC_OK) { delete t; return rc; }
+        DeviceScope dev(device);
+        if (!dev.ok) { set_error("mdc_trainer_create: cannot select device %d", device); delete t; return MDC_EIO; }
+        const size_t pb = t->P * sizeof(float);
+        auto fail = [&](int code) { mdc_trainer_destroy(t); return code; };
+        if (hipMalloc(&t->d_params, pb) != hipSuccess || hipMalloc(&t->d_m, pb) != hipSuccess || hipMalloc(&t->d_v, pb) != hipSuccess ||
+            hipMalloc(&t->d_grad, pb) != hipSuccess || hipMalloc(&t->d_partials, pb * kMaxWaves) != hipSuccess ||
+            hipMalloc(&t->d_loss_partials, sizeof(double) * kMaxWaves) != hipSuccess || hipMalloc(&t->d_state, sizeof(TrainState)) != hipSuccess) {
+            set_error("mdc_trainer_create: out of device memory");
+            return fail(MDC_ENOMEM);
+        }
+        if (hipMemset(t->d_params, 0, pb) != hipSuccess || hipMemset(t->d_m, 0, pb) != hipSuccess || hipMemset(t->d_v, 0, pb) != hipSuccess ||
+            hipMemset(t->d_grad, 0, pb) != hipSuccess || hipMemset(t->d_state, 0, sizeof(TrainState)) != hipSuccess) {
+            set_error("mdc_trainer_create: hipMemset failed");
+            return fail(MDC_EIO);
+        }
+        *out = t;
+        return MDC_OK;
+    });
+}
+
+int mdc_trainer_num_layers(const mdc_trainer* t) {
+    if (!t) { set_error("null trainer"); return MDC_EINVAL; }
+    return t->nlayers;
+}
+
+int mdc_trainer_layer_sizes(const mdc_trainer* t, int layer, size_t* kernel_elems, size_t* bias_elems) {
+    if (!t || layer < 0 || layer >= t->nlayers) { set_error("mdc_trainer_layer_sizes: bad layer %d", layer); return MDC_EINVAL; }
+    if (kernel_elems) *kernel_elems = t->nk[layer];
+    if (bias_elems) *bias_elems = t->nb[layer];
+    return MDC_OK;
+}
+
+int mdc_trainer_set_adam(mdc_trainer* t, float lr, float beta1, float beta2, float eps) {
+    if (!t) { set_error("null trainer"); return MDC_EINVAL; }
+    if (!(lr > 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) {
+        set_error("mdc_trainer_set_adam: need lr > 0, 0 <= beta < 1, eps >= 0");
+        return MDC_EINVAL;
+    }
+    t->lr = lr; t->beta1 = beta1; t->beta2 = beta2; t->eps = eps;
+    return MDC_OK;
+}
+
+// which: 0 weights, 1 Adam m, 2 Adam v, 3 gradient of the last batch
+static float* trainer_vec(mdc_trainer* t, int which) {
+    switch (which) {
+        case MDC_TRAIN_WEIGHTS: return t->d_params;
+        case MDC_TRAIN_ADAM_M:  return t->d_m;
+        case MDC_TRAIN_ADAM_V:  return t->d_v;
+        case MDC_TRAIN_GRADIENT: return t->d_grad;
+        default: return nullptr;
+    }
+}
+
+int mdc_trainer_set_tensor(mdc_trainer* t, int which, int layer, const float* kernel_host, size_t kernel_elems, const float* bias_host,
+                           size_t bias_elems, void* hip_stream) {
+    return guarded("mdc_trainer_set_tensor", [&]() -> int {
+        if (!t || !kernel_host || !bias_host) { set_error("mdc_trainer_set_tensor: null argument"); return MDC_EINVAL; }
+        if (layer < 0 || layer >= t->nlayers) { set_error("mdc_trainer_set_tensor: layer %d out of range 0..%d", layer, t->nlayers - 1); return MDC_EINVAL; }
+        float* vec = trainer_vec(t, which);
+        if (!vec || which == MDC_TRAIN_GRADIENT) { set_error("mdc_trainer_set_tensor: `which` must be MDC_TRAIN_WEIGHTS, _ADAM_M or _ADAM_V"); return MDC_EINVAL; }
+        if (kernel_elems != t->nk[layer] || bias_elems != t->nb[layer]) {
+            set_error("mdc_trainer_set_tensor: layer %d expects kernel %zu / bias %zu elements, got %zu / %zu", layer, t->nk[layer], t->nb[layer],
+                      kernel_elems, bias_elems);
+            return MDC_EINVAL;
+        }
+        DeviceScope dev(t->device);
+        if (!dev.ok) { set_error("mdc_trainer_set_tensor: cannot select device %d", t->device); return MDC_EIO; }
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        MDC_HIP(hipMemcpyAsync(vec + t->off_k[layer], kernel_host, kernel_elems * sizeof(float), hipMemcpyHostToDevice, s));
+        MDC_HIP(hipMemcpyAsync(vec + t->off_b[layer], bias_host, bias_elems * sizeof(float), hipMemcpyHostToDevice, s));
+        MDC_HIP(hipStreamSynchronize(s));      // the host buffers are the caller's again on return
+        if (which == MDC_TRAIN_WEIGHTS) t->have[layer] = true;
+        return MDC_OK;
+    });
+}
+
+int mdc_trainer_get_tensor(mdc_trainer* t, int which, int layer, float* kernel_host, size_t kernel_elems, float* bias_host, size_t bias_elems,
+                           void* hip_stream) {
+    return guarded("mdc_trainer_get_tensor", [&]() -> int {
+        if (!t || !kernel_host || !bias_host) { set_error("mdc_trainer_get_tensor: null argument"); return MDC_EINVAL; }
+        if (layer < 0 || layer >= t->nlayers) { set_error("mdc_trainer_get_tensor: layer %d out of range 0..%d", layer, t->nlayers - 1); return MDC_EINVAL; }
+        float* vec = trainer_vec(t, which);
+        if (!vec) { set_error("mdc_trainer_get_tensor: unknown tensor kind %d", which); return MDC_EINVAL; }
+        if (kernel_elems != t->nk[layer] || bias_elems != t->nb[layer]) {
+            set_error("mdc_trainer_get_tensor: layer %d holds kernel %zu / bias %zu elements, asked for %zu / %zu", layer, t->nk[layer], t->nb[layer],
+                      kernel_elems, bias_elems);
+            return MDC_EINVAL;
+        }
+        DeviceScope dev(t->device);
+        if (!dev.ok) { set_error("mdc_trainer_get_tensor: cannot select device %d", t->device); return MDC_EIO; }
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        MDC_HIP(hipMemcpyAsync(kernel_host, vec + t->off_k[layer], kernel_elems * sizeof(float), hipMemcpyDeviceToHost, s));
+        MDC_HIP(hipMemcpyAsync(bias_host, vec + t->off_b[layer], bias_elems * sizeof(float), hipMemcpyDeviceToHost, s));
+        MDC_HIP(hipStreamSynchronize(s));
+        return MDC_OK;
+    });
+}
+
+int mdc_trainer_set_iterations(mdc_trainer* t, int64_t iterations, void* hip_stream) {
+    return guarded("mdc_trainer_set_iterations", [&]() -> int {
+        if (!t || iterations < 0) { set_error("mdc_trainer_set_iterations: bad argument"); return MDC_EINVAL; }
+        DeviceScope dev(t->device);
+        if (!dev.ok) { set_error("mdc_trainer_set_iterations: cannot select device %d", t->device); return MDC_EIO; }
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        long long v = iterations;
+        MDC_HIP(hipMemcpyAsync(&static_cast<TrainState*>(t->d_state)->iterations, &v, sizeof(v), hipMemcpyHostToDevice, s));
+        MDC_HIP(hipStreamSynchronize(s));
+        return MDC_OK;
+    });
+}
+
+int mdc_train_batch(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first, int64_t count, int apply,
+                    void* hip_stream) {
+    return guarded("mdc_train_batch", [&]() -> int {
+        int rc = check_batch_args("mdc_train_batch", t, x_dev, y_dev, first, count);
+        if (rc != MDC_OK) return rc;
+        if (count == 0) return MDC_OK;
+        DeviceScope dev(t->device);
+        if (!dev.ok) { set_error("mdc_train_batch: cannot select device %d", t->device); return MDC_EIO; }
+        return launch_batch(t, x_dev, y_dev, order_dev, first, count, apply ? 2 : 1, static_cast<hipStream_t>(hip_stream));
+    });
+}
+
+int mdc_trainer_evaluate(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first, int64_t count,
+                         void* hip_stream) {
+    return guarded("mdc_trainer_evaluate", [&]() -> int {
+        int rc = check_batch_args("mdc_trainer_evaluate", t, x_dev, y_dev, first, count);
+        if (rc != MDC_OK) return rc;
+        if (count == 0) return MDC_OK;
+        DeviceScope dev(t->device);
+        if (!dev.ok) { set_error("mdc_trainer_evaluate: cannot select device %d", t->device); return MDC_EIO; }
+        return launch_batch(t, x_dev, y_dev, order_dev, first, count, 0, static_cast<hipStream_t>(hip_stream));
+    });
+}
+
+int mdc_trainer_read(mdc_trainer* t, int reset, double* train_loss_sum, int64_t* train_frames, double* eval_loss_sum, int64_t* eval_frames,
+                     int64_t* iterations, void* hip_stream) {
+    return guarded("mdc_trainer_read", [&]() -> int {
+        if (!t) { set_error("null trainer"); return MDC_EINVAL; }
+        DeviceScope dev(t->device);
+        if (!dev.ok) { set_error("mdc_trainer_read: cannot select device %d", t->device); return MDC_EIO; }
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        TrainState h{};
+        MDC_HIP(hipMemcpyAsync(&h, t->d_state, sizeof(h), hipMemcpyDeviceToHost, s));
+        MDC_HIP(hipStreamSynchronize(s));
+        if (train_loss_sum) *train_loss_sum = h.train_loss;
+        if (train_frames) *train_frames = h.train_frames;
+        if (eval_loss_sum) *eval_loss_sum = h.eval_loss;
+        if (eval_frames) *eval_frames = h.eval_frames;
+        if (iterations) *iterations = h.iterations;
+        if (reset) {
+            // zero the four accumulators behind `iterations` (which is optimizer state, not a statistic)
+            MDC_HIP(hipMemsetAsync(reinterpret_cast<char*>(t->d_state) + offsetof(TrainState, train_frames), 0,
+                                   sizeof(TrainState) - offsetof(TrainState, train_frames), s));
+            MDC_HIP(hipStreamSynchronize(s));
+        }
+        return MDC_OK;
+    });
+}
+
+void mdc_trainer_destroy(mdc_trainer* t) {
+    if (!t) return;
+    {
+        DeviceScope dev(t->device);
+        for (void* p : {(void*)t->d_params, (void*)t->d_m, (void*)t->d_v, (void*)t->d_grad, (void*)t->d_partials, (void*)t->d_loss_partials, t->d_state})
+            if (p) (void)hipFree(p);
+    }
+    delete t;
+}
+
+}  // extern "C"

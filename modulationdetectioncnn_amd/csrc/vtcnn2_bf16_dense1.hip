@@ -308,16 +308,28 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
     bf16x8 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
     u32x2 ra[4][2];      // F8: a unit's raw fragments between the ds_read_b64 and the conversion
 
+    // F8 fragment reads are issued as asm ds_read_b64, one per fragment (round 5).  Left to hipcc, pairs of them 1 KiB x k
+    // apart were merged into ds_read2st64_b64 (8 of them + 16 ds_read_b64 in round 4's ISA), and a ds_read2_b64 is served
+    // in four 16-lane groups over 32 banks -- not the 2 x 32 lanes over 64 banks the source swizzle was derived for:
+    // SQ_LDS_BANK_CONFLICT was 0.29 of the LDS-active cycles against 0.015 in bf16 mode (profiles/r04_mfma.json).
+    // Address of fragment (i, ks): row u = 64 wr + 16 i + fr (64 B each), chunk ((2 ks + fg/2) ^ ((u>>2)&3)) * 16, half
+    // (fg & 1) * 8.  (u>>2)&3 = (fr>>2)&3 whatever i and wr, and 2 ks only flips bit 1 of the chunk: one per-lane
+    // address for ks = 0, the same with bit 5 flipped for ks = 1, i * 1024 as the instruction's offset.
+    unsigned ra_lane[2] = {0u, 0u};
+    if constexpr (F8) {
+        ra_lane[0] = (unsigned)((64 * wr + fr) * 64 + ((((fg >> 1) ^ ((fr >> 2) & 3)) * 16) + (fg & 1) * 8));
+        ra_lane[1] = ra_lane[0] ^ 32u;
+    }
     auto read_a = [&](bf16x8 (&a)[4][2], int unit, int b) {
         const unsigned char* base = smem + ((size_t)b * 4 + unit) * kUnitBytes;
-        if constexpr (F8) {      // row u (64 B), bytes 32 ks + 8 fg .. +7: chunk (2 ks + fg/2) ^ ((u>>2)&3), half fg & 1
+        if constexpr (F8) {
+            const unsigned bl = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)const_cast<unsigned char*>(base);
+            const unsigned ad0 = bl + ra_lane[0], ad1 = bl + ra_lane[1];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int u = 64 * wr + 16 * i + fr;
-                    ra[i][ks] = *reinterpret_cast<const u32x2*>(base + u * 64 + (((ks * 2 + (fg >> 1)) ^ ((u >> 2) & 3)) * 16) + (fg & 1) * 8);
-                }
+            for (int i = 0; i < 4; ++i) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ra[i][0]) : "v"(ad0), "i"(i * 1024) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ra[i][1]) : "v"(ad1), "i"(i * 1024) : "memory");
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -385,13 +397,17 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
     };
 #define D1_WAIT_BARRIER(N) do { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #define D1_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    // ... and where the asm-issued E4M3 fragments (ra) are consumed: hipcc neither counts those reads nor knows that the wait
+    // produces them, so the wait names them as in/out operands -- no conversion can be scheduled in front of it
+#define D1_LGKM_RA() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), \
+                                  "+v"(ra[2][0]), "+v"(ra[2][1]), "+v"(ra[3][0]), "+v"(ra[3][1]) :: "memory")
 
     // ---- prologue: tile 0 complete in buffer 0; a0 of tile 0 in registers
 #pragma unroll
     for (int u = 0; u < 4; ++u) stage_unit(0, u, 0);
     D1_WAIT_BARRIER(0);
     read_a(a0, 0, 0);
-    if constexpr (F8) { D1_LGKM(); cvt_a(a0); }
+    if constexpr (F8) { D1_LGKM_RA(); cvt_a(a0); }
 #ifndef D1_NOSTAGGER
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs half a phase behind
 #endif
@@ -428,9 +444,8 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         __builtin_amdgcn_sched_barrier(0);
         read_a(a1, 3, b);
         if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier();
-        D1_LGKM();
-        if constexpr (F8) quadrant_cv(a1, b1, 4, 2, a1, std::true_type{});
-        else quadrant(a1, b1, 4, 2);
+        if constexpr (F8) { D1_LGKM_RA(); quadrant_cv(a1, b1, 4, 2, a1, std::true_type{}); }
+        else { D1_LGKM(); quadrant(a1, b1, 4, 2); }
         __builtin_amdgcn_s_barrier();
         // phase 3: quadrant (a1, b0); a0 of tile t+1
         if (more) stage_unit(t + 1, 3, b ^ 1);
@@ -439,9 +454,9 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         if constexpr (F8) { if (more) D1_WAIT_BARRIER(3); else __builtin_amdgcn_s_barrier(); }
         else { if (more) D1_WAIT_BARRIER(4); else __builtin_amdgcn_s_barrier(); }
         if constexpr (F8) {
-            D1_LGKM();      // the next tile's a0 bytes (read before the barrier above) are converted under this quadrant's MFMAs
-            if (more) quadrant_cv(a1, b0, 4, 0, a0, std::false_type{});
-            else quadrant(a1, b0, 4, 0);
+            // the next tile's a0 bytes (read before the barrier above) are converted under this quadrant's MFMAs
+            if (more) { D1_LGKM_RA(); quadrant_cv(a1, b0, 4, 0, a0, std::false_type{}); }
+            else { D1_LGKM(); quadrant(a1, b0, 4, 0); }
         } else {
             quadrant(a1, b0, 4, 0);
             D1_LGKM();
@@ -453,6 +468,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
 #endif
 #undef D1_WAIT_BARRIER
 #undef D1_LGKM
+#undef D1_LGKM_RA
 
     d1_epilogue<HEAD>(acc, smem, row0, n, lane, wv, c1, hid, w2pack, n_out, probs, labels);
 }

@@ -316,3 +316,234 @@ def load_keras_h5(path: str) -> KerasCheckpoint:
         layer_names=layer_names,
         weights=weights,
     )
+
+
+# ======================================================================================================================
+# Writer: the file ModelCheckpoint(filepath, ...) leaves behind (cnn.py:143-147; CNN.ipynb cell 8) -- a Keras 2.4
+# full-model save -- so that weights trained HERE flow back into the reference's pipeline (its model.load_weights, then
+# float2fix and the ROM tables).  Same subset of HDF5 as the reader, the way libhdf5 1.10 lays the bundled files out:
+# superblock v0, old-style groups (local heap + v1 B-tree + symbol-table nodes, names sorted), v1 object headers,
+# contiguous little-endian datasets, v1 attributes (fixed strings, or variable-length strings in one global heap).
+# tests/test_h5_writer.py holds a written file against the real libhdf5 of this image (h5dump: same tree, attributes and
+# data as the reference's own file) and against the reader above.
+# ======================================================================================================================
+_LEAF_K, _INTERNAL_K = 4, 16          # symbol-table node = 2*4 entries; B-tree node = 2*16 children (libhdf5's defaults)
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\0" * (-len(b) % 8)
+
+
+# datatype messages (version 1), as libhdf5 encodes the types h5py hands it
+_DT_F32 = bytes.fromhex("11201f00040000000000200017080017" "7f000000")
+_DT_F64 = bytes.fromhex("11203f000800000000004000340b0034" "ff030000")
+_DT_I64 = bytes.fromhex("100800000800000000004000")
+
+
+def _dt_fixed_string(size: int) -> bytes:
+    return struct.pack("<BBBBI", 0x13, 0x01, 0, 0, size)          # class 3, null-padded, ASCII
+
+
+def _dt_vlen_string(utf8: bool) -> bytes:
+    return struct.pack("<BBBBI", 0x19, 0x01, 0x01 if utf8 else 0x00, 0, 16) + bytes.fromhex("100000000100000000000800")
+
+
+def _dataspace(shape: Optional[Tuple[int, ...]]) -> bytes:
+    if shape is None or len(shape) == 0:
+        return struct.pack("<BBBB4x", 1, 0, 0, 0)                 # scalar
+    dims = b"".join(struct.pack("<Q", d) for d in shape)
+    return struct.pack("<BBBB4x", 1, len(shape), 1, 0) + dims + dims
+
+
+class _Node:
+    def __init__(self, name: str):
+        self.name = name
+        self.attrs: List[Tuple[str, bytes, bytes, bytes]] = []      # (name, datatype, dataspace, data)
+        self.children: Dict[str, "_Node"] = {}
+        self.array: Optional[np.ndarray] = None                     # datasets only
+
+    def group(self, name: str) -> "_Node":
+        return self.children.setdefault(name, _Node(name))
+
+    def dataset(self, name: str, array: np.ndarray) -> None:
+        node = _Node(name)
+        node.array = array
+        self.children[name] = node
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(96)            # superblock, written last
+        self.vlen: List[bytes] = []
+        self.gcol_addr = 96                 # the global heap collection follows the superblock
+
+    def alloc(self, data: bytes) -> int:
+        addr = len(self.buf)
+        self.buf += _pad8(data)
+        return addr
+
+    # -- global heap: every variable-length string of the file in ONE collection ---------------------------------
+    def vlen_ref(self, s: str) -> bytes:
+        self.vlen.append(s.encode("utf-8"))
+        return struct.pack("<IQI", len(self.vlen[-1]), self.gcol_addr, len(self.vlen))
+
+    def gcol_blob(self) -> bytes:
+        body = b"".join(struct.pack("<HHIQ", i + 1, 0, 0, len(s)) + _pad8(s) for i, s in enumerate(self.vlen))
+        size = max(4096, (16 + len(body) + 16 + 4095) // 4096 * 4096)      # libhdf5's minimum collection is 4 KiB
+        free = size - 16 - len(body)                                         # object 0 = the free space, its own header included
+        blob = b"GCOL" + struct.pack("<B3xQ", 1, size) + body + struct.pack("<HHIQ", 0, 0, 0, free)
+        return blob + b"\0" * (size - len(blob))
+
+    # -- messages ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _msg(mtype: int, flags: int, data: bytes) -> bytes:
+        data = _pad8(data)
+        return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+    def _attr_msg(self, name: str, dt: bytes, ds: bytes, data: bytes) -> bytes:
+        nm = name.encode("ascii") + b"\0"
+        return self._msg(0x0C, 4, struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(ds)) + _pad8(nm) + _pad8(dt) + _pad8(ds) + data)
+
+    def _header(self, msgs: List[bytes]) -> int:
+        body = b"".join(msgs)
+        return self.alloc(struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(body)) + body)
+
+    # -- objects ----------------------------------------------------------------------------------------------------
+    def write(self, node: _Node) -> Tuple[int, int, int]:
+        """Post-order: children first.  Returns (object header address, B-tree address, heap address); the last two are 0
+        for a dataset."""
+        attrs = [self._attr_msg(*a) for a in node.attrs]
+        if node.array is not None:
+            a = node.array
+            dt = {np.dtype("<f4"): _DT_F32, np.dtype("<i8"): _DT_I64}[a.dtype]
+            raw = a.tobytes()
+            data_addr = self.alloc(raw)
+            msgs = [self._msg(0x01, 0, _dataspace(a.shape)), self._msg(0x03, 1, dt), self._msg(0x05, 1, bytes([2, 2, 2, 1, 0, 0, 0, 0])),
+                    self._msg(0x08, 0, struct.pack("<BBQQ", 3, 1, data_addr, len(raw)))]
+            return self._header(msgs + attrs), 0, 0
+        kids = sorted(node.children.values(), key=lambda c: c.name.encode("ascii"))      # libhdf5 orders by strcmp
+        placed = [(c, *self.write(c)) for c in kids]
+        # local heap: "" at offset 0, then the names; no free block (free-list head = 1, libhdf5's H5HL_FREE_NULL)
+        seg, offs = bytearray(8), []
+        for c in kids:
+            offs.append(len(seg))
+            seg += _pad8(c.name.encode("ascii") + b"\0")
+        seg_addr = self.alloc(bytes(seg))
+        heap_addr = self.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(seg), 1, seg_addr))
+        # symbol-table nodes of <= 2*_LEAF_K entries, one leaf B-tree node over them
+        per = 2 * _LEAF_K
+        snods, keys = [], [0]
+        for s in range(0, max(len(kids), 1), per):
+            part = placed[s:s + per]
+            ents = b""
+            for j, (c, hdr, bt, hp) in enumerate(part):
+                cache = 1 if c.array is None else 0
+                ents += struct.pack("<QQII", offs[s + j], hdr, cache, 0) + (struct.pack("<QQ", bt, hp) if cache else bytes(16))
+            ents += bytes(40 * (per - len(part)))
+            snods.append(self.alloc(b"SNOD" + struct.pack("<BBH", 1, 0, len(part)) + ents))
+            keys.append(offs[s + len(part) - 1] if part else 0)
+        if len(snods) > 2 * _INTERNAL_K:
+            raise H5FormatError("too many members for a one-level group B-tree")
+        tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods), _UNDEF, _UNDEF) + struct.pack("<Q", keys[0])
+        for child, key in zip(snods, keys[1:]):
+            tree += struct.pack("<QQ", child, key)
+        tree += bytes(24 + 8 * (2 * _INTERNAL_K + 1) + 8 * 2 * _INTERNAL_K - len(tree))
+        bt_addr = self.alloc(tree)
+        hdr = self._header([self._msg(0x11, 0, struct.pack("<QQ", bt_addr, heap_addr))] + attrs)
+        return hdr, bt_addr, heap_addr
+
+    def finish(self, root: _Node) -> bytes:
+        """Every vlen_ref() has been taken by now (attributes are built before this call), so the collection's size is known
+        and it goes right behind the superblock, where vlen_ref() said it would be."""
+        assert len(self.buf) == 96 == self.gcol_addr
+        self.buf += self.gcol_blob()
+        hdr, bt, hp = self.write(root)
+        sb = _SIG + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", _LEAF_K, _INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", 0, _UNDEF, len(self.buf), _UNDEF)
+        sb += struct.pack("<QQII", 0, hdr, 1, 0) + struct.pack("<QQ", bt, hp)
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def _attr_strings(w: _Writer, node: _Node, name: str, values: List[str]) -> None:
+    """h5py's encoding of a list of str attribute: fixed-length, null-padded ASCII; an EMPTY list becomes float64 (0,)."""
+    if not values:
+        node.attrs.append((name, _DT_F64, _dataspace((0,)), b""))
+        return
+    enc = [v.encode("ascii") for v in values]
+    size = max(len(e) for e in enc)
+    node.attrs.append((name, _dt_fixed_string(size), _dataspace((len(enc),)), b"".join(e.ljust(size, b"\0") for e in enc)))
+
+
+def _attr_vlen(w: _Writer, node: _Node, name: str, value: str, utf8: bool) -> None:
+    node.attrs.append((name, _dt_vlen_string(utf8), _dataspace(None), w.vlen_ref(value)))
+
+
+KERAS_VERSION, KERAS_BACKEND = "2.4.0", "tensorflow"      # what the five bundled files say of themselves
+
+
+def write_keras_h5(path: str, topology, weights, optimizer: Optional[dict] = None, adam: Optional[dict] = None,
+                   layer_names: Optional[Dict[str, str]] = None, model_name: str = "sequential") -> None:
+    """Write a Keras 2.4 full-model checkpoint: what ``ModelCheckpoint(filepath, ...)`` (cnn.py:143) saves and
+    ``model.load_weights(filepath)`` (cnn.py:147) reads back.
+
+    topology: modulationdetectioncnn_amd.Topology; weights: [(kernel, bias)] per weighted layer in Keras' layouts;
+    optimizer: {'iterations': int, 'm': [(k, b)], 'v': [(k, b)]} -> the /optimizer_weights group (omitted when None, as
+    Keras omits it for an optimizer that has not stepped); adam: {'lr', 'beta1', 'beta2', 'eps'} for training_config.
+    layer_names: Keras' auto-generated names by role (Topology.keras_layer_names()); a fresh session's by default."""
+    from ..topology import keras_model_config, keras_training_config      # (formats <- topology only here: writer-side JSON)
+    names = topology.keras_layer_names(layer_names)
+    shapes = topology.layer_shapes
+    if len(weights) != len(shapes):
+        raise ValueError(f"expected {len(shapes)} (kernel, bias) pairs, got {len(weights)}")
+    f32 = lambda a, shape: _checked(a, shape)
+    w = _Writer()
+    root = _Node("/")
+    cfg_json = json.dumps(keras_model_config(topology, names, model_name))
+    train_json = json.dumps(keras_training_config(adam or {}))
+    _attr_vlen(w, root, "keras_version", KERAS_VERSION, True)
+    _attr_vlen(w, root, "backend", KERAS_BACKEND, True)
+    _attr_vlen(w, root, "model_config", cfg_json, False)
+    _attr_vlen(w, root, "training_config", train_json, False)
+    mw = root.group("model_weights")
+    _attr_strings(w, mw, "layer_names", [n for _, n in names])
+    _attr_vlen(w, mw, "backend", KERAS_BACKEND, False)
+    _attr_vlen(w, mw, "keras_version", KERAS_VERSION, False)
+    weighted = [n for role, n in names if role in ("conv", "dense")]
+    if len(weighted) != len(shapes):
+        raise H5FormatError("layer naming and weight list disagree")
+    it = iter(zip(weights, shapes))
+    for role, lname in names:
+        g = mw.group(lname)
+        if role not in ("conv", "dense"):
+            _attr_strings(w, g, "weight_names", [])
+            continue
+        (k, b), (ks, bs) = next(it)
+        _attr_strings(w, g, "weight_names", [f"{lname}/kernel:0", f"{lname}/bias:0"])
+        inner = g.group(lname)
+        inner.dataset("kernel:0", f32(k, ks))
+        inner.dataset("bias:0", f32(b, bs))
+    if optimizer is not None:
+        ow = root.group("optimizer_weights")
+        wn = ["Adam/iter:0"] + [f"Adam/{l}/{t}/{mv}:0" for mv in ("m", "v") for l in weighted for t in ("kernel", "bias")]
+        _attr_strings(w, ow, "weight_names", wn)
+        ad = ow.group("Adam")
+        ad.dataset("iter:0", np.asarray(int(optimizer["iterations"]), dtype="<i8"))
+        for mv in ("m", "v"):
+            if len(optimizer[mv]) != len(shapes):
+                raise ValueError(f"optimizer[{mv!r}] needs one (kernel, bias) pair per weighted layer")
+            for lname, (k, b), (ks, bs) in zip(weighted, optimizer[mv], shapes):
+                lg = ad.group(lname)
+                lg.group("kernel").dataset(f"{mv}:0", f32(k, ks))
+                lg.group("bias").dataset(f"{mv}:0", f32(b, bs))
+    blob = w.finish(root)
+    with open(path, "wb") as fh:
+        fh.write(blob)
+
+
+def _checked(a, shape) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(a), dtype="<f4")
+    if tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected a tensor of shape {tuple(shape)}, got {a.shape}")
+    return a

@@ -4,6 +4,9 @@
     -----------------------------------------------    -----------------------------------
     model = models.Sequential(); model.add(...)        m = VTCNN2(Topology.deployed(3))
     model.load_weights(filepath)      cnn.py:147       m.load_weights(path)   (.h5 | .txt | .npz)
+    model.compile(loss=..., optimizer='adam') :113     m.compile(loss='categorical_crossentropy', optimizer='adam')
+    history = model.fit(X, Y, ...)    cnn.py:135       history = m.fit(X, Y, batch_size=1024, epochs=100, validation_data=...,
+                                                                       checkpoint=filepath, patience=5)   (training.py)
     model.predict(X, batch_size=1024) cnn.py:198       m.predict(X, batch_size=1024)
     int(np.argmax(Y_hat[i,:]))        cnn.py:209       m.predict_classes(X)
     Model(inputs, layers[i].output)   CNN.ipynb c.17   m.predict(X, tap='conv'|'flat'|'dense')
@@ -172,11 +175,63 @@ class VTCNN2:
             out.append((k, b))
         self._weights = out
         self._release()
+        self._drop_trainer()        # weights set from outside: the optimizer state that went with the old ones is void
 
     def get_weights(self) -> Weights:
         if self._weights is None:
             raise RuntimeError("no weights loaded")
         return [(k.copy(), b.copy()) for k, b in self._weights]
+
+    # ------------------------------------------------------------------ training (cnn.py:113, 122-147)
+    def compile(self, loss: str = "categorical_crossentropy", optimizer: str = "adam", lr: float = 1e-3, beta1: float = 0.9,
+                beta2: float = 0.999, eps: float = 1e-7) -> None:
+        """``model.compile(loss='categorical_crossentropy', optimizer='adam')`` (cnn.py:113): the one loss and the one
+        optimizer the reference uses; the keyword arguments are keras.optimizers.Adam's (its defaults)."""
+        if loss != "categorical_crossentropy" or str(optimizer).lower() != "adam":
+            raise ValueError("the reference compiles with loss='categorical_crossentropy', optimizer='adam'; nothing else is built")
+        self._adam = dict(lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps))
+        self._drop_trainer()
+
+    def _drop_trainer(self) -> None:
+        t = getattr(self, "_trainer", None)
+        if t is not None:
+            t.close()
+        self._trainer = None
+
+    def trainer(self):
+        """The training state behind fit(): created on first use from the current weights; it lives on (as a compiled Keras
+        model's optimizer does) until the weights are replaced from outside."""
+        from .training import Trainer
+        if getattr(self, "_trainer", None) is None:
+            if self._weights is None:
+                raise RuntimeError("set or load weights (or VTCNN2.synthetic) before fit()")
+            self._trainer = Trainer(self.topology, self._weights, device=self.device_index, _lib_variant=self._lib_variant,
+                                    **getattr(self, "_adam", {}))
+        return self._trainer
+
+    def fit(self, X, Y, batch_size: int = 1024, epochs: int = 100, validation_data=None, patience: Optional[int] = 5,
+            checkpoint: Optional[str] = None, shuffle: bool = True, seed: Optional[int] = None, verbose: int = 0, **kw):
+        """``model.fit(X_train, Y_train, batch_size, epochs, validation_data=(X_test, Y_test), callbacks=[ModelCheckpoint(
+        checkpoint, monitor='val_loss', save_best_only=True), EarlyStopping(monitor='val_loss', patience=patience)])``
+        (cnn.py:135-146) for the deployed and cnn.py nets, f32, on the MI355X (csrc/train.hip).  As in Keras the model is
+        left with the LAST epoch's weights; the best ones are in `checkpoint` (a Keras full-model .h5: ``load_weights`` it,
+        as cnn.py:147 does) and in the returned history's ``best_weights``."""
+        t = self.trainer()
+        hist = t.fit(X, Y, batch_size=batch_size, epochs=epochs, validation_data=validation_data, patience=patience,
+                     checkpoint=checkpoint, shuffle=shuffle, seed=seed, verbose=verbose, **kw)
+        self._weights = t.get_weights()
+        self._release()                     # the inference engine re-packs the new weights on its next use
+        return hist
+
+    def save(self, filepath: str) -> None:
+        """``model.save(filepath)``: Keras 2.4 full-model HDF5 (formats/h5mini.write_keras_h5); Adam's state is included when
+        this model has been fitted."""
+        from .formats.h5mini import write_keras_h5
+        if self._weights is None:
+            raise RuntimeError("no weights loaded")
+        t = getattr(self, "_trainer", None)
+        write_keras_h5(filepath, self.topology, self._weights, optimizer=t.optimizer_state() if t is not None else None,
+                       adam=getattr(self, "_adam", None) or {})
 
     # ------------------------------------------------------------------ engine
     def _lib(self):
@@ -243,6 +298,7 @@ class VTCNN2:
     def __del__(self):
         try:
             self._release()
+            self._drop_trainer()
         except Exception:
             pass
 

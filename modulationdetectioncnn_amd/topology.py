@@ -176,3 +176,119 @@ def synthetic_frames(n: int, seed: int = 2016, sigma: float = 5e-3, device=None)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     return torch.randn((n, 2, 128), generator=g, device=device, dtype=torch.float32) * sigma
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Keras-side description of a topology: what a full-model .h5 carries in its `model_config` / `training_config`
+# attributes (formats/h5mini.write_keras_h5).  Key order and values follow the bundled files' own JSON (Keras 2.4.0).
+# ----------------------------------------------------------------------------------------------------------------------
+def _keras_roles(kind: str) -> List[str]:
+    """The Sequential's layers by role, in order (cnn.py:104-112; CNN.ipynb cell 6; the DeepSig notebook :229-243)."""
+    if kind == "deployed":
+        return ["reshape", "pad", "conv", "flatten", "dense", "activation", "reshape"]
+    if kind == "cnnpy":
+        return ["reshape", "pad", "conv", "flatten", "dense", "dense", "activation", "reshape"]
+    if kind == "vtcnn2":
+        return ["reshape", "pad", "conv", "dropout", "pad", "conv", "dropout", "flatten", "dense", "dropout", "dense", "activation", "reshape"]
+    raise ValueError(kind)
+
+
+_KERAS_BASENAME = {"reshape": "reshape", "pad": "zero_padding2d", "conv": "conv2d", "dropout": "dropout", "flatten": "flatten",
+                   "dense": "dense", "activation": "activation"}
+
+
+def _topology_keras_layer_names(self, override=None) -> List[Tuple[str, str]]:
+    """[(role, Keras layer name)]: the names a fresh Keras session generates (reshape, zero_padding2d, conv2d, flatten,
+    dense, dense_1, activation, reshape_1), or `override` -- a list of names, one per layer, e.g. the bundled files'
+    reshape_6 / zero_padding2d_3 / ... -- to reproduce an existing file's."""
+    roles = _keras_roles(self.kind)
+    if override is not None:
+        override = list(override)
+        if len(override) != len(roles):
+            raise ValueError(f"need {len(roles)} layer names, got {len(override)}")
+        return list(zip(roles, override))
+    seen: dict = {}
+    out = []
+    for r in roles:
+        k = seen.get(r, 0)
+        seen[r] = k + 1
+        out.append((r, _KERAS_BASENAME[r] + (f"_{k}" if k else "")))
+    return out
+
+
+Topology.keras_layer_names = _topology_keras_layer_names
+
+
+def _init(name: str) -> dict:
+    return {"class_name": name, "config": {"seed": None}} if name != "Zeros" else {"class_name": "Zeros", "config": {}}
+
+
+def _conv_cfg(name, filters, ksize, data_format, first):
+    cfg = {"name": name, "trainable": True}
+    if first is not None:
+        cfg["batch_input_shape"] = first
+    cfg.update({"dtype": "float32", "filters": filters, "kernel_size": list(ksize), "strides": [1, 1], "padding": "valid",
+                "data_format": data_format, "dilation_rate": [1, 1], "groups": 1, "activation": "relu", "use_bias": True,
+                "kernel_initializer": _init("GlorotUniform"), "bias_initializer": _init("Zeros"), "kernel_regularizer": None,
+                "bias_regularizer": None, "activity_regularizer": None, "kernel_constraint": None, "bias_constraint": None})
+    return {"class_name": "Conv2D", "config": cfg}
+
+
+def _dense_cfg(name, units, activation):
+    return {"class_name": "Dense", "config": {
+        "name": name, "trainable": True, "dtype": "float32", "units": units, "activation": activation, "use_bias": True,
+        "kernel_initializer": _init("HeNormal"), "bias_initializer": _init("Zeros"), "kernel_regularizer": None,
+        "bias_regularizer": None, "activity_regularizer": None, "kernel_constraint": None, "bias_constraint": None}}
+
+
+def keras_model_config(topo: Topology, names: Sequence[Tuple[str, str]], model_name: str = "sequential") -> dict:
+    """The `model_config` JSON of a Keras 2.4 save of this Sequential.  For the deployed nets it reproduces the bundled
+    files' attribute byte for byte (tests/test_h5_writer.py) -- including `batch_input_shape: [null, 1, 2, 128]` on the
+    Conv2D, the reference's stray `input_shape=(1, 2, 128)` argument (CNN.ipynb cell 6; cnn.py:108)."""
+    F, D, C = topo.filters, topo.hidden, topo.classes
+    cf = topo.kind == "vtcnn2"
+    fmt = "channels_first" if cf else "channels_last"
+    target = {"deployed": [2, 128, 1], "cnnpy": [1, 2, 128], "vtcnn2": [1, 2, 128]}[topo.kind]
+    pad = 2 if cf else 1
+    convs = {"deployed": [(F, (1, 2))], "cnnpy": [(F, (1, 2))], "vtcnn2": [(256, (1, 3)), (80, (2, 3))]}[topo.kind]
+    denses = {"deployed": [(C, "relu")], "cnnpy": [(D, "relu"), (C, "linear")], "vtcnn2": [(256, "relu"), (C, "linear")]}[topo.kind]
+    layers = [{"class_name": "InputLayer", "config": {"batch_input_shape": [None, 2, 128], "dtype": "float32", "sparse": False,
+                                                       "ragged": False, "name": names[0][1] + "_input"}}]
+    ci = di = ri = 0
+    for role, name in names:
+        if role == "reshape":
+            cfg = {"name": name, "trainable": True}
+            if ri == 0:
+                cfg["batch_input_shape"] = [None, 2, 128]
+            cfg.update({"dtype": "float32", "target_shape": target if ri == 0 else [C]})
+            layers.append({"class_name": "Reshape", "config": cfg})
+            ri += 1
+        elif role == "pad":
+            layers.append({"class_name": "ZeroPadding2D", "config": {"name": name, "trainable": True, "dtype": "float32",
+                                                                     "padding": [[0, 0], [pad, pad]], "data_format": fmt}})
+        elif role == "conv":
+            f, ks = convs[ci]
+            layers.append(_conv_cfg(name, f, ks, fmt, [None, 1, 2, 128] if ci == 0 and not cf else None))
+            ci += 1
+        elif role == "dropout":
+            layers.append({"class_name": "Dropout", "config": {"name": name, "trainable": True, "dtype": "float32", "rate": 0.5,
+                                                               "noise_shape": None, "seed": None}})
+        elif role == "flatten":
+            layers.append({"class_name": "Flatten", "config": {"name": name, "trainable": True, "dtype": "float32", "data_format": fmt}})
+        elif role == "dense":
+            u, act = denses[di]
+            layers.append(_dense_cfg(name, u, act))
+            di += 1
+        elif role == "activation":
+            layers.append({"class_name": "Activation", "config": {"name": name, "trainable": True, "dtype": "float32", "activation": "softmax"}})
+    return {"class_name": "Sequential", "config": {"name": model_name, "layers": layers}}
+
+
+def keras_training_config(adam: dict) -> dict:
+    """`training_config` of model.compile(loss='categorical_crossentropy', optimizer='adam') (cnn.py:113): Keras stores the
+    float32 hyper-parameters as the doubles they round-trip to; epsilon is a Python float."""
+    f = lambda v: float(np.float32(v))
+    return {"loss": "categorical_crossentropy", "metrics": None, "weighted_metrics": None, "loss_weights": None,
+            "optimizer_config": {"class_name": "Adam", "config": {
+                "name": "Adam", "learning_rate": f(adam.get("lr", 1e-3)), "decay": 0.0, "beta_1": f(adam.get("beta1", 0.9)),
+                "beta_2": f(adam.get("beta2", 0.999)), "epsilon": float(adam.get("eps", 1e-7)), "amsgrad": False}}}

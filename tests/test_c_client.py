@@ -16,8 +16,12 @@ CFLAGS = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I",
 
 def test_header_is_plain_c99(tmp_path):
     tu = tmp_path / "only_header.c"
-    tu.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 3 ? 0 : 1; }\n')
+    tu.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 5 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(tu)], check=True)
+    # ... and the value is checked for real (the line above only parses): compile, run, exit code 0
+    exe = tmp_path / "only_header"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(tu), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
 
 
 def test_c_client_compiles_and_links_without_cxx_or_torch(tmp_path):

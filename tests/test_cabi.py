@@ -24,7 +24,30 @@ def test_library_exports_every_declared_symbol():
         L = ctypes.CDLL(lib)
         for name in _declared():
             assert hasattr(L, name), (variant, name)
-        assert L.mdc_abi_version() == _cabi.ABI_VERSION == 4
+        assert L.mdc_abi_version() == _cabi.ABI_VERSION == 5
+
+
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """Built with -fvisibility=hidden + a linker version script: `nm -D --defined-only` of either library lists the C
+    entry points of include/mdc.h and NOTHING else -- no mangled mdc:: helpers, no libstdc++ template instantiations, no
+    hipcc markers (35 C++ functions used to be exported next to the 25 C ones)."""
+    import subprocess
+    import modulationdetectioncnn_amd.build as b
+    for variant in b.VARIANTS:
+        out = subprocess.run(["nm", "-D", "--defined-only", b.build(variant=variant)], capture_output=True, text=True, check=True).stdout
+        assert sorted(line.split()[-1] for line in out.splitlines() if line.strip()) == _declared(), variant
+
+
+def test_trainer_entry_points_validate_their_arguments_without_gpu():
+    L = _cabi.lib()
+    L.mdc_last_error.restype = ctypes.c_char_p
+    assert L.mdc_trainer_create(None, 0, None) == -22 and b"null" in L.mdc_last_error()
+    assert L.mdc_train_batch(None, None, None, None, 0, 1, 1, None) == -22 and b"null trainer" in L.mdc_last_error()
+    assert L.mdc_trainer_evaluate(None, None, None, None, 0, 1, None) == -22
+    assert L.mdc_trainer_num_layers(None) == -22
+    assert L.mdc_trainer_set_adam(None, 1e-3, 0.9, 0.999, 1e-7) == -22
+    assert L.mdc_trainer_read(None, 0, None, None, None, None, None, None) == -22
+    L.mdc_trainer_destroy(None)
 
 
 def test_product_library_has_one_kernel_per_role_and_never_reads_the_environment():
@@ -93,7 +116,7 @@ def test_header_is_plain_c99(tmp_path):
     """include/mdc.h compiles as C99 with -Wall -Werror -pedantic and nothing but the standard headers."""
     import subprocess
     src = tmp_path / "hdr.c"
-    src.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 4 && MDC_HOP_FRAME == 128 && MDC_OPT_ALL == 1 && MDC_OPT_FP8_BF16_FEATURES == 1 ? 0 : 1; }\n')
+    src.write_text('#include "mdc.h"\nint main(void) { return MDC_ABI_VERSION == 5 && MDC_HOP_FRAME == 128 && MDC_OPT_ALL == 1 && MDC_OPT_FP8_BF16_FEATURES == 1 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "hdr")], check=True)
     assert subprocess.run([str(tmp_path / "hdr")]).returncode == 0
 

@@ -51,3 +51,35 @@ def test_lint_flags_the_pattern():
     assert len(lint.lint(short)) == 1
     waited = ["ds_write_b128 v10, v[20:23]", "s_waitcnt lgkmcnt(0)", "v_mfma_f32_16x16x16_bf16 v[20:23], v[1:2], v[3:4], 0"]
     assert lint.lint(waited) == []
+
+
+def _tool(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+@pytest.mark.parametrize("inst", ["ILi0ELb1ELb1", "ILi0ELb0ELb1"])      # <ABL 0, HEAD, F8 = true>
+def test_dense1_fp8_mode_reads_its_fragments_with_plain_ds_read_b64(inst):
+    """hipcc merged half of the E4M3 fragment reads into ds_read2st64_b64, whose 4 x 16-lane / 32-bank
+    service the source swizzle was not derived for (LDS bank conflicts 0.29 of the LDS-active cycles).  They are asm
+    ds_read_b64 now; no two-address 64-bit read may come back."""
+    lint = _tool("lint_async_hazards")
+    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", "vtcnn2_bf16_dense1.hip"), "vt_dense1_bf16_phased_kernel" + inst)
+    assert sum(1 for x in isa if x.startswith("v_mfma_f32_16x16x32")) >= 64
+    assert not [x for x in isa if x.startswith(("ds_read2_b64", "ds_read2st64_b64"))]
+    assert sum(1 for x in isa if x.startswith("ds_read_b64")) == 32       # prologue + phase 2 + phase 3 (two code paths): 8 each
+    assert lint.lint(isa) == []
+
+
+def test_no_product_kernel_uses_scratch():
+    """Every kernel of the BUILT libmdc.so: .private_segment_fixed_size == 0 and no VGPR spill (round 4 shipped
+    deployed_q612_kernel<10> with 22 VGPRs in scratch).  Read from the library's own code objects, not from a recompile."""
+    import modulationdetectioncnn_amd.build as b
+    meta = _tool("kernel_meta").kernel_metadata(b.build(variant="product"))
+    assert len(meta) >= 60
+    assert any("deployed_q612_kernel" in k for k in meta) and any("train_deployed_kernel" in k for k in meta)
+    bad = {k: r for k, r in meta.items() if r["scratch"] != 0 or r["vgpr_spill"] != 0}
+    assert not bad, bad

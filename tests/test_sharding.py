@@ -238,8 +238,10 @@ def _bench_worker(rank, world, port, out_dir):
     bench.select_device = lambda d: None
     bench.dominant_roofline = lambda *a, **k: ({"bound": "mfma", "frac": 0.0}, {})
     buf = io.StringIO()
+    os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)      # a rank started by SOMEONE ELSE's launcher, bare environment
     with contextlib.redirect_stdout(buf):
         bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "1", "--no-extras", "--no-cpu-baseline"])
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"   # ... gets the dmabuf-IPC switch RCCL needs all the same
     with open(os.path.join(out_dir, f"out{rank}.txt"), "w") as f:
         f.write(buf.getvalue())
     # every rank ran the headline and then the two other readings, each on ITS shard (strong: 2^20 / world frames)
@@ -283,6 +285,7 @@ class _Stub:
 
 def run_workload(name, device, steps, warmup, dist=None, frames=None):
     rank = dist.get_rank() if dist else 0
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"      # the self-launched ranks' environment (the parent had none)
     bench.agree_ok(dist, True, name)
     el = timed_region(lambda: time.sleep(0.01 * (rank + 1)), steps, warmup)
     return _Stub(), None, None, None, (2048 if frames is None else frames), el
@@ -302,7 +305,8 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):
     import subprocess
     wrapper = tmp_path / "bench_stub.py"
     wrapper.write_text(_STUB_WRAPPER.format(root=ROOT))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "HSA_ENABLE_IPC_MODE_LEGACY")}
     env["MDC_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, str(wrapper), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=300)
@@ -317,6 +321,78 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):
     assert list(j)[-1] == "legs" and j["legs"] == j["config"]["legs_frames_per_s_and_roofline_frac"]
     assert j["legs"]["vtcnn2-c11-bf16-n2^20"] == [round(j["value"]), 0.5] and len(j["legs"]) == 3
     assert "starting" in r.stderr and "torch.distributed.run" in r.stderr
+
+
+_SLEEPER_WRAPPER = """
+import os, sys, time
+sys.path.insert(0, {root!r})
+import bench
+
+
+def run_workload(name, device, steps, warmup, dist=None, frames=None):
+    open(os.path.join({out!r}, "rank%d.pid" % dist.get_rank()), "w").write(str(os.getpid()))
+    time.sleep(120)
+
+
+bench.run_workload = run_workload
+bench.select_device = lambda d: None
+sys.exit(bench.main(script=os.path.abspath(__file__)))
+"""
+
+
+def test_self_launched_ranks_do_not_outlive_a_terminated_parent(tmp_path):
+    """a driver timeout (SIGTERM to `python bench.py --gpus 2`) must take the launcher and BOTH ranks with it --
+    orphans would keep their GPUs."""
+    import signal
+    import subprocess
+    import time
+    wrapper = tmp_path / "bench_sleeper.py"
+    wrapper.write_text(_SLEEPER_WRAPPER.format(root=ROOT, out=str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MDC_BENCH_BACKEND"] = "gloo"
+    parent = subprocess.Popen([sys.executable, str(wrapper), "--gpus", "2", "--no-extras", "--no-cpu-baseline"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        deadline = time.time() + 120
+        files = [tmp_path / "rank0.pid", tmp_path / "rank1.pid"]
+        while time.time() < deadline and not all(f.exists() and f.read_text().strip() for f in files):
+            assert parent.poll() is None, parent.stderr.read()[-2000:]
+            time.sleep(0.2)
+        pids = [int(f.read_text()) for f in files]
+        parent.send_signal(signal.SIGTERM)
+        assert parent.wait(timeout=40) == 128 + signal.SIGTERM
+
+        def alive(pid):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                return False
+            try:      # (a zombie still answers signal 0: look at its state)
+                return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+            except OSError:
+                return False
+        t_end = time.time() + 20
+        while time.time() < t_end and any(alive(p) for p in pids):
+            time.sleep(0.2)
+        assert not any(alive(p) for p in pids), pids
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+
+
+def test_init_distributed_binds_rccl_to_the_ranks_gpu(monkeypatch):
+    """nccl (= RCCL) gets device_id = this rank's GPU, so the communicator is built on it explicitly; gloo takes none."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    seen = []
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: seen.append((backend, kw)))
+    bench.init_distributed(3, "nccl")
+    bench.init_distributed(3, "gloo")
+    assert seen == [("nccl", {"device_id": torch.device("cuda", 3)}), ("gloo", {})]
+    env = bench.rank_environment({})
+    assert env == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"} and bench.rank_environment({"HSA_ENABLE_IPC_MODE_LEGACY": "1"}) == {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}
 
 
 def test_bench_refuses_a_launcher_whose_world_size_disagrees(monkeypatch, capsys):
