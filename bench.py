@@ -42,7 +42,16 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0                                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}  # dense MFMA peaks (no sparsity)
-PEAK_VALU_F32_TFLOPS = 157.3                                 # same guide: vector f32 peak (= the f32 matrix rate)
+PEAK_VALU_F32_TFLOPS = 157.3                                 # same guide: vector f32 peak (= the f32 matrix rate) at the 2.4 GHz spec clock
+# What an FMA stream can ISSUE on this chip, measured (HISTORY.md 4.1; tools/microbench/gen_valu_banks.py, random mantissas, two
+# or more waves per SIMD, wall time): one wave64 v_fma_f32 per 1.06 ns per SIMD -- 2 cycles at the ~1.9 GHz the chip holds under a
+# vector load, not at 2.4 -- = 64 lanes x 2 FLOP x 1,024 SIMDs / 1.06 ns; v_pk_fma_f32 takes 2.28 ns (two FMAs per lane in the
+# time of two v_fma_f32: packing saves issue slots, not time).  The VALU-bound legs report their fraction of BOTH.
+VALU_F32_ISSUE_CEILING_TFLOPS = 64 * 2 * 1024 / 1.06e-9 / 1e12      # 123.6
+# Integer roof of the Q6.12 legs: every 18 x 18-bit product pair is two v_mad_i64_i32, which issue at HALF the plain VALU rate
+# (profiles/r03_imul_rate.log: 9.5 cycles per wave-instruction, 2.38 per SIMD with four waves) -> 64 lanes / 2.38 cycles x 1,024
+# SIMDs x 2.4 GHz multiply-accumulates per second
+INT_MAC_ISSUE_PEAK_TMACS = 64 / 2.38 * 1024 * 2.4e9 / 1e12           # 66.1
 # deployed legs whose bounding roof is the f32 vector ALU, not HBM (the 10-filter net at every dtype's
 # conv, the 3-filter net once its input is 256 B of raw bytes): they report bound = "valu" with the HBM fraction beside it
 VALU_BOUND = {("deployed", 10, "f32", "frames"), ("deployed", 10, "f32", "u8"), ("deployed", 3, "f32", "u8"),
@@ -193,9 +202,13 @@ def dominant_roofline(m, x, probs, labels, steps):
                                       "(bench.live_traffic), per launch, gfx950 corrections applied")
         else:
             traffic, tsrc = measured_traffic(f"{name}/{m.dtype}", frames_per_launch)
+        # the WHOLE step against the same roof (SURVEY.md 8(d)'s 38,252,032 FLOP per frame at C = 11): every kernel's launch time
+        step_ms = sum(v[0] for v in prof.values()) / steps
+        whole = topo.flops_per_frame * n / (step_ms * 1e-3) / 1e12
         rl = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
               "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
-              "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
+              "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
+              "whole_step_frac": whole / peak, "whole_step_achieved": whole, "whole_step_kernel_ms": step_ms}
     else:
         rl = deployed_roofline(topo, m.dtype, name, avg_ms, frames_per_launch, "frames")
     return rl, kernels
@@ -211,7 +224,10 @@ def deployed_roofline(topo, dtype, name, avg_ms, frames_per_launch, source):
     if (topo.kind, topo.filters, dtype, source) in VALU_BOUND:
         tf = topo.flops_per_frame * frames_per_launch / (avg_ms * 1e-3) / 1e12
         return {"bound": "valu", "kernel": name, "achieved": tf, "peak": PEAK_VALU_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / PEAK_VALU_F32_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms,
+                "frac": tf / PEAK_VALU_F32_TFLOPS, "peak_is": "vector f32 spec peak (256 CUs x 2.4 GHz x 256 FLOP/clk)",
+                "issue_ceiling": VALU_F32_ISSUE_CEILING_TFLOPS, "frac_of_issue_ceiling": tf / VALU_F32_ISSUE_CEILING_TFLOPS,
+                "issue_ceiling_is": "measured: one wave64 v_fma_f32 per 1.06 ns per SIMD on random data (v_pk_fma_f32: 2.28 ns), HISTORY.md 4.1",
+                "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms,
                 "frames_per_launch": frames_per_launch, "hbm_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
     return {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
             "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch}
@@ -423,10 +439,80 @@ def run_q612(filters, device, steps=10, warmup=3, n=1 << 20):
     el = timed_region(lambda: m.predict_q612(x, as_float=False), steps, warmup, sync=torch.cuda.synchronize, device=x.device)
     gbs = (1024 + 16) * n * steps / el / 1e9
     traffic, tsrc = measured_traffic(f"mdc_deployed_q612/F{filters}", n)
+    # algorithmic integer work: one 18 x 18-bit multiply-accumulate per conv tap and per dense weight = 258 F (2 + 3) per frame
+    tmacs = 258 * filters * 5 * n * steps / el / 1e12
     return {"workload": f"deployed{filters}-q612-n2^20", "value": n * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
-            "dtype": "int18/int32 (Q6.12)", "roofline": {"bound": "int-valu", "kernel": "mdc_deployed_q612", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
-                                                        "from": "wall time incl. two small output allocations, one launch per step; HBM fraction reported, the bound is 64-bit integer VALU"}}
+            "dtype": "int18/int32 (Q6.12)",
+            "roofline": {"bound": "int-valu", "kernel": "mdc_deployed_q612", "achieved": tmacs, "peak": INT_MAC_ISSUE_PEAK_TMACS, "unit": "TMAC/s",
+                         "frac": tmacs / INT_MAC_ISSUE_PEAK_TMACS,
+                         "peak_is": "issue rate of v_mad_i64_i32 (half the plain VALU rate, profiles/r03_imul_rate.log) x 64 lanes x 1,024 SIMDs x 2.4 GHz; "
+                                    "the bit selection {m[35], m[28:12]}, the 18-bit wraps and the wave reductions come on top of the multiplies",
+                         "hbm_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
+                         "from": "wall time incl. two small output allocations, one launch per step"}}
+
+
+def run_training(device, epochs=20):
+    """Extra leg: the training step of SURVEY.md 8(f) item 4 at the reference's own geometry -- CNN.ipynb cell 5 / 7: 18,900
+    training frames, batch_size 1024 (18 full batches + one of 468), Adam -- for the two deployed nets and cnn.py's literal
+    one.  Frames resident in HBM, an epoch = 19 x 2 launches enqueued back to back with its shuffle as an index array, one
+    synchronisation per epoch; beside it the same epoch replayed as ONE captured hipGraph, and the numpy oracle's
+    train_step on this box's host cores (a port, NOT Keras)."""
+    import torch
+    from modulationdetectioncnn_amd import Topology, synthetic_weights, synthetic_frames
+    from modulationdetectioncnn_amd.training import Trainer, to_onehot
+    from oracle import oracle_train as OT      # cpu baseline only
+    n, batch = 18900, 1024
+    rows = []
+    for tag, kind, topo in (("deployed3", "deployed", Topology.deployed(3, 3)), ("deployed10", "deployed", Topology.deployed(10, 3)),
+                            ("cnnpy", "cnnpy", Topology.cnnpy(10, 10, 5))):
+        w = synthetic_weights(topo, seed=2016)
+        x = synthetic_frames(n, seed=2016, device=f"cuda:{device}") * (1.0 if kind == "deployed" else 40.0)
+        lab = torch.randint(0, topo.classes, (n,), device=x.device)
+        tr = Trainer(topo, w, device=device)
+        xd, yd = tr._frames(x), tr._targets(lab, n)
+        order = torch.randperm(n, device=x.device).to(torch.int32)
+
+        def epoch():
+            for s0 in range(0, n, batch):
+                tr.train_batch(xd, yd, order, s0, min(batch, n - s0))
+        epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            epoch()
+            tr.read()                                   # the epoch's one synchronisation (fit reads loss / val_loss here)
+        el = (time.perf_counter() - t0) / epochs
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                epoch()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            g.replay()
+        torch.cuda.synchronize()
+        elg = (time.perf_counter() - t0) / epochs
+        steps_per_epoch = (n + batch - 1) // batch
+        xb = x[:batch].cpu().numpy()
+        yb = to_onehot(lab[:batch].cpu().numpy(), topo.classes)
+        wo = [(k.copy(), b.copy()) for k, b in w]
+        opt = OT.KerasAdam([t.shape for t in OT.flatten_weights(wo)])
+        OT.train_step(kind, xb, yb, wo, opt, np.float32)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            OT.train_step(kind, xb, yb, wo, opt, np.float32)
+        cpu = (time.perf_counter() - t0) / 5
+        rows.append({"net": tag, "frames_per_s": n / el, "epoch_ms": el * 1e3, "us_per_step": el / steps_per_epoch * 1e6,
+                     "graph_replay_epoch_ms": elg * 1e3, "graph_replay_frames_per_s": n / elg,
+                     "cpu_port_ms_per_step": cpu * 1e3, "cpu_port_frames_per_s": batch / cpu})
+        tr.close()
+    return {"workload": "training step (forward + loss + backward + Adam), 18,900 frames per epoch in batches of 1,024 (CNN.ipynb cell 5/7), f32",
+            "unit": "frames/s", "value": rows[0]["frames_per_s"], "rows": rows,
+            "note": "launch-latency bound at this batch: 1,024 frames x 2,334 parameters per step; cpu_port = numpy oracle_train.train_step, not Keras"}
 
 
 def run_host_path(device, steps=4, warmup=1):
@@ -699,6 +785,11 @@ def main(argv=None, script=None):
                                "unit": "us", "rows": latency.rows(device, sizes=(1, 16, 64, 4096), reps=100)})
             except Exception as e:
                 extras.append({"workload": "latency", "error": repr(e)})
+            try:      # the training step at the reference's batch geometry
+                extras.append(run_training(device))
+                torch.cuda.empty_cache()
+            except Exception as e:
+                extras.append({"workload": "training step", "error": repr(e)})
             try:      # numpy in, numpy out: what cnn.py:198 hands over (never the headline value)
                 extras.append(run_host_path(device))
             except Exception as e:

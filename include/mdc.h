@@ -143,6 +143,13 @@ MDC_API int mdc_finalize(mdc_model* m, int dtype);
  * reference's bundled frames).  It fixes the power-of-two scale of the fp8 activations. */
 MDC_API int mdc_set_fp8_input_absmax(mdc_model* m, float absmax);
 
+/* MDC_KIND_VTCNN2 at MDC_FP8 with E4M3 features (the default), before mdc_finalize: the largest conv2 + ReLU output the
+ * features must represent, e.g. twice the largest MDC_TAP_CONV value a bf16 / f32 forward of a sample batch produced
+ * (calibration).  It fixes the power-of-two scale of the E4M3 bytes: values up to 2 x absmax keep their e4m3 precision,
+ * larger ones saturate.  Not called: the library estimates it from the weights (12 sigma of the conv2 sum for independent
+ * samples of rms fp8_input_absmax / 4).  Added in ABI 5. */
+MDC_API int mdc_set_fp8_feature_absmax(mdc_model* m, float absmax);
+
 /* Bytes of caller-owned device scratch ONE mdc_forward call of n frames needs (0 for deployed / cnnpy).
  * MDC_KIND_VTCNN2 keeps a call's conv2 features there: n rounded up to 256 frames x (10,560 features x 2 B in the
  * bf16 / fp8 modes, 4 B at f32, + 1 KiB of hidden layer) = 22,144 B (f32: 43,264 B) per frame -- 1.45 GB for a

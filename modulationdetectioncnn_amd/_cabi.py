@@ -25,7 +25,7 @@ EXPORTS = [
     "mdc_profile_name", "mdc_profile_read", "mdc_profile_reset", "mdc_last_error", "mdc_destroy",
     "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax",
     "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8",
-    "mdc_crossentropy",
+    "mdc_crossentropy", "mdc_set_fp8_feature_absmax",
     "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_tensor",
     "mdc_trainer_get_tensor", "mdc_trainer_set_iterations", "mdc_train_batch", "mdc_trainer_evaluate", "mdc_trainer_read",
     "mdc_trainer_destroy",
@@ -83,6 +83,7 @@ def lib(variant: str = "product") -> C.CDLL:
     L.mdc_confusion.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     L.mdc_iq_u8_to_frames.argtypes = [vp, i64, C.c_float, vp, vp]
     L.mdc_set_fp8_input_absmax.argtypes = [vp, C.c_float]
+    L.mdc_set_fp8_feature_absmax.argtypes = [vp, C.c_float]
     L.mdc_forward_iq_u8.argtypes = [vp, vp, i64, i64, C.c_float, vp, vp, vp, sz, vp]
     L.mdc_confusion_binned.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.mdc_iq_u8_windows.argtypes = [vp, i64, i64, C.c_float, vp, vp]
@@ -105,7 +106,7 @@ def lib(variant: str = "product") -> C.CDLL:
     for name in ("mdc_create", "mdc_num_layers", "mdc_layer_sizes", "mdc_set_weights", "mdc_finalize",
                  "mdc_forward", "mdc_set_profiling", "mdc_profile_slots", "mdc_profile_read", "mdc_profile_reset",
                  "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax", "mdc_forward_iq_u8",
-                 "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8", "mdc_crossentropy",
+                 "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8", "mdc_crossentropy", "mdc_set_fp8_feature_absmax",
                  "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_tensor",
                  "mdc_trainer_get_tensor", "mdc_trainer_set_iterations", "mdc_train_batch", "mdc_trainer_evaluate", "mdc_trainer_read"):
         getattr(L, name).restype = i32

@@ -60,11 +60,13 @@ __device__ __forceinline__ int quant(float v) {                  // float2fix: t
 // the position-0 weights [h][f][c], then the per-lane tables [slot][lane]; dense (n,C) / labels (n): each may be NULL
 struct QParams { const void* x; int x_is_q; long n; const int* tab; int* dense; int* labels; };
 
-// Occupancy: the 3-filter kernel fits two waves per SIMD (104 VGPRs); the 10-filter one keeps 120 weight registers per lane
-// and under a 256-register budget spilled 22 of them to scratch (84 B per lane, round 4) -- it gets the whole register
-// file (one wave per SIMD, no scratch; A/B in profiles/r05_q612_occupancy_ab.log).
+// Registers: the 3-filter kernel fits two waves per SIMD with room to spare (104 VGPRs).  The 10-filter one kept 120 weight
+// registers per lane and, under the 256-register budget of two waves per SIMD, spilled 22 VGPRs to scratch (84 B per
+// lane, round 4).  Round 5: one wave per SIMD removes the spill but costs the latency hiding (2.92 ms per 2^20 frames
+// against 2.2 ms at best, profiles/r05_q612_occupancy1_ab.log), so instead the second position slot's 60 weights live in
+// LDS ([entry][lane] per wave: conflict-free ds_read_b32, 15 KiB per wave) and the kernel keeps two waves per SIMD.
 template <int F>
-__global__ __launch_bounds__(256, F == 10 ? 1 : 2) void deployed_q612_kernel(const void* __restrict__ px, int x_is_q, long pn, const int* __restrict__ ptab,
+__global__ __launch_bounds__(256, 2) void deployed_q612_kernel(const void* __restrict__ px, int x_is_q, long pn, const int* __restrict__ ptab,
                                                                int* __restrict__ pdense, int* __restrict__ plabels) {
     const QParams p{px, x_is_q, pn, ptab, pdense, plabels};
     constexpr int kW0 = 64;                          // position-0 weights [h][f][c]
@@ -74,7 +76,11 @@ __global__ __launch_bounds__(256, F == 10 ? 1 : 2) void deployed_q612_kernel(con
     const int* k1 = p.tab + F;
     const int* cb = p.tab + 2 * F;
     const int* db = p.tab + 3 * F;
-    int wd[2][F][kQC][2];                            // [position slot][filter][class][row table I/Q]
+    constexpr bool WLDS = F == 10;                   // slot 1's weights in LDS (see above)
+    constexpr int kRegSlots = WLDS ? 1 : 2;
+    __shared__ int sw[WLDS ? 4 * F * kQC * 2 * 64 : 1];      // [wave][(f*C + c)*2 + h][lane]
+    int* swv = sw + (WLDS ? (threadIdx.x >> 6) * (F * kQC * 2 * 64) : 0);
+    int wd[kRegSlots][F][kQC][2];                    // [position slot][filter][class][row table I/Q]
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -82,7 +88,12 @@ __global__ __launch_bounds__(256, F == 10 ? 1 : 2) void deployed_q612_kernel(con
 #pragma unroll
             for (int c = 0; c < kQC; ++c)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) wd[s][f][c][h] = p.tab[kLaneTab + ((((s * F + f) * kQC + c) * 2 + h) << 6) + lane];
+                for (int h = 0; h < 2; ++h) {
+                    const int v = p.tab[kLaneTab + ((((s * F + f) * kQC + c) * 2 + h) << 6) + lane];
+                    if (s < kRegSlots) wd[s][f][c][h] = v;
+                    else swv[(((f * kQC + c) * 2 + h) << 6) + lane] = v;      // (read back by this lane only: no barrier)
+                }
+    auto wq = [&](int s, int f, int c, int h) -> int { return s < kRegSlots ? wd[s < kRegSlots ? s : 0][f][c][h] : swv[(((f * kQC + c) * 2 + h) << 6) + lane]; };
 
     const long nblk = (p.n + 63) >> 6;
     const long nwaves = (long)gridDim.x * 4;
@@ -103,6 +114,7 @@ __global__ __launch_bounds__(256, F == 10 ? 1 : 2) void deployed_q612_kernel(con
         int x00 = 0, x10 = 0;                        // lane i: quantised x[0][0], x[1][0] of frame base + i
         int2 nI = load(base, 0), nQ = load(base, 1);
         for (int it = 0; it < cnt; ++it) {
+            if (WLDS) asm volatile("" ::: "memory");      // keep the LDS weight reads inside the loop (hoisted, they are 60 registers again)
             const int2 xi = nI, xq = nQ;
             nI = load(base + it + 1, 0);             // one frame ahead
             nQ = load(base + it + 1, 1);
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256, F == 10 ? 1 : 2) void deployed_q612_kernel(con
                     aq = aq < 0 ? 0 : aq;
 #pragma unroll
                     for (int c = 0; c < kQC; ++c)
-                        acc[c] += (unsigned)pair18(ai, wd[s][f][c][0], aq, wd[s][f][c][1]);      // sign-extended 18-bit term, 32-bit wrap
+                        acc[c] += (unsigned)pair18(ai, wq(s, f, c, 0), aq, wq(s, f, c, 1));      // sign-extended 18-bit term, 32-bit wrap
                 }
             // wave sum (wrap-around adds commute): every lane ends up with the total
 #pragma unroll

@@ -268,6 +268,15 @@ int mdc_set_fp8_input_absmax(mdc_model* m, float absmax) {
     return MDC_OK;
 }
 
+int mdc_set_fp8_feature_absmax(mdc_model* m, float absmax) {
+    if (!m) { set_error("null model"); return MDC_EINVAL; }
+    if (m->finalized) { set_error("mdc_set_fp8_feature_absmax: call it before mdc_finalize"); return MDC_ESTATE; }
+    if (m->topo.kind != MDC_KIND_VTCNN2) { set_error("mdc_set_fp8_feature_absmax: the E4M3 features exist for MDC_KIND_VTCNN2 only"); return MDC_EINVAL; }
+    if (!(absmax > 0.f) || !(absmax < 1e30f)) { set_error("mdc_set_fp8_feature_absmax: need a positive finite value"); return MDC_EINVAL; }
+    m->fp8_feature_absmax = absmax;
+    return MDC_OK;
+}
+
 int mdc_forward_q612(const mdc_model* m, const void* x_dev, int x_is_q612, int64_t n, int32_t* dense_dev, int32_t* labels_dev,
                      void* hip_stream) {
     return guarded("mdc_forward_q612", [&]() -> int {

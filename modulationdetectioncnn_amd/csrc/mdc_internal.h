@@ -123,6 +123,7 @@ struct mdc_model {
     int alt = 0;
     int alt_ring = -1;           // alternates build, MDC_DEP_RING=N: ring depth of the 3-filter f32 kernel (0 = direct loads); -1 = the product's choice
     float fp8_input_absmax = 0.02f;
+    float fp8_feature_absmax = 0.f;   // vtcnn2 at MDC_FP8, E4M3 features: the caller's measured largest conv2 feature (0 = estimate it from the weights)
     int fp8_feat_scale_log2 = 0;
     bool fp8_e4m3_features = false;   // vtcnn2 at MDC_FP8 without MDC_OPT_FP8_BF16_FEATURES: the workspace features are E4M3 bytes (x 2^feat_scale_log2)
     float fp8_feat_divisor = 1.f;     // ... and this is what the conv kernel's finish divides its sums (true x 2^-32) by before rounding them

@@ -22,14 +22,12 @@
 // Intermediate layout in HBM (workspace): feat[frame][w][o]  (o fastest, 80 per position).
 // dense1's weight rows are permuted to that order at pack time, so the reference's
 // channels_first Flatten is never materialised (only the 'flat'/'conv' taps un-permute).
-#include "mdc_internal.h"
+#include "dense_chain_common.h"      // (mdc_internal.h, f32x4, the head's softmax + argmax epilogue)
 
 #include <algorithm>
 #include <cmath>
 
 namespace mdc {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 namespace {
 
@@ -180,15 +178,158 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------
-// f32 dense1: hid[f][n] = relu(sum_k feat[f][k] W1p[k][n] + c1[n]),  M = frames, K = 10560,
-// N = 256.  128x128 tile, BK = 32, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x4 tiles.
+// f32 dense1: hid[f][n] = relu(sum_k feat[f][k] W1p[k][n] + c1[n]),  M = frames, K = 10560, N = 256, on
+// v_mfma_f32_16x16x4_f32 (exact f32 fma chains, K ascending: the order IS the result).
+//
+// Round 5: one work-group holds a 128-frame x 256-unit tile -- ALL hidden units of its frames -- so
+//  * every feature row is read from HBM once (the 128 x 128 tiles of rounds 1-4 read it once per column half: 86,978 B per
+//    frame through the PMC counters against 42,240 + 1,024 needed);
+//  * HEAD = true runs dense2 + softmax + first-max argmax in the epilogue, on the hidden tile in LDS, with the head
+//    kernel's own instruction chain (dense_chain_common.h: same operands, same order, same bits as the mdc_vt_head
+//    launch): the hidden layer neither goes to HBM nor comes back, and the f32 batch path is two launches, not three.
+// 8 waves (2 x 4), each 64 x 64 = 4 x 4 MFMA tiles, BK = 32, two LDS buffers filled through registers one K-tile ahead
+// (global loads issued before a tile's MFMAs, LDS writes after them: one barrier per K-tile).  LDS images chosen for the
+// fragment reads: A as [row][36] (a lane reads A[row = lane&15][k = kk + (lane>>4)]: bank 36 row + k, all 64 distinct),
+// B as [k][272] (bank 16 (lane>>4) + (lane&15) + const: all 64 distinct); both are written with 16-byte stores.
+// The per-element accumulation order (K-tiles ascending, k-steps of 4 ascending, one MFMA chain per output tile) is that
+// of the old kernel and of vt_dense1_f32_small_kernel: bit-identical hidden layer (tests/test_fullsize_gpu.py).
 // ------------------------------------------------------------------------------------
-constexpr int kDM = 128, kDN = 128, kDK = 32, kDld = 129;
+constexpr int kDM = 128, kDK = 32;
+constexpr int kDAld = 36, kDBld = 272;
+constexpr int kDABuf = kDM * kDAld, kDBBuf = kDK * kDBld;                    // floats per buffer
+constexpr size_t kDense1F32Lds = (size_t)kDM * kChainXld * sizeof(float);   // the epilogue's [128][260] image (133,120 B) > 2 x (A + B) = 106,496 B
+static_assert(kDense1F32Lds >= 2 * (kDABuf + kDBBuf) * sizeof(float), "the staging buffers must fit under the epilogue image");
 
-__global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restrict__ feat, long n,
+template <bool HEAD>
+__global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restrict__ feat, long n,
                                                             const float* __restrict__ w1p,   // [10560][256]
                                                             const float* __restrict__ c1,    // [256]
-                                                            float* __restrict__ hid) {       // [n][256]
+                                                            float* __restrict__ hid,         // [n][256] (HEAD = false)
+                                                            const float* __restrict__ w2pack, int n_out,
+                                                            float* __restrict__ probs, int* __restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* As = dsm;                    // [2][128][36]
+    float* Bs = dsm + 2 * kDABuf;       // [2][32][272]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long row0 = (long)blockIdx.x * kDM;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: A tile 128 rows x 32 k = 1024 float4, two per thread (8 consecutive threads = one row's 128 B);
+    //          B tile 32 k x 256 cols = 2048 float4, four per thread (one wave = one k row's 1 KiB)
+    const int ar0 = tid >> 3, ak4 = (tid & 7) * 4;           // A rows ar0 and ar0 + 64
+    const int bk0 = tid >> 6, bc4 = (tid & 63) * 4;           // B rows bk0, +8, +16, +24
+    const bool aok0 = row0 + ar0 < n, aok1 = row0 + ar0 + 64 < n;      // rows past the end: zeros, computed, never stored
+    const float* ap0 = feat + (aok0 ? row0 + ar0 : 0) * (long)kFeat + ak4;
+    const float* ap1 = feat + (aok1 ? row0 + ar0 + 64 : 0) * (long)kFeat + ak4;
+    // (named registers, not arrays: hipcc kept float4 arrays captured by these lambdas in scratch)
+    float4 ga0, ga1, gb0, gb1, gb2, gb3;
+    const float* bp = w1p + (size_t)bk0 * kHid + bc4;
+    auto fetch = [&](int k0) {
+        // (the address is always valid -- clamped to row 0 --, the VALUE is selected: `ok ? *p : zero` made hipcc select
+        // between two addresses and park the zeros in scratch)
+        ga0 = *reinterpret_cast<const float4*>(ap0 + k0);
+        ga1 = *reinterpret_cast<const float4*>(ap1 + k0);
+        if (!aok0) ga0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!aok1) ga1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* b = bp + (size_t)k0 * kHid;
+        gb0 = *reinterpret_cast<const float4*>(b);
+        gb1 = *reinterpret_cast<const float4*>(b + 8 * kHid);
+        gb2 = *reinterpret_cast<const float4*>(b + 16 * kHid);
+        gb3 = *reinterpret_cast<const float4*>(b + 24 * kHid);
+    };
+    auto stash = [&](int b) {
+        float* a = As + b * kDABuf + ar0 * kDAld + ak4;
+        *reinterpret_cast<float4*>(a) = ga0;
+        *reinterpret_cast<float4*>(a + 64 * kDAld) = ga1;
+        float* d = Bs + b * kDBBuf + bk0 * kDBld + bc4;
+        *reinterpret_cast<float4*>(d) = gb0;
+        *reinterpret_cast<float4*>(d + 8 * kDBld) = gb1;
+        *reinterpret_cast<float4*>(d + 16 * kDBld) = gb2;
+        *reinterpret_cast<float4*>(d + 24 * kDBld) = gb3;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    constexpr int kTiles = kFeat / kDK;      // 330
+    for (int t = 0; t < kTiles; ++t) {
+        const int b = t & 1;
+        if (t + 1 < kTiles) fetch((t + 1) * kDK);
+        const float* Ab = As + b * kDABuf + (wr * 64 + fr) * kDAld + fq;
+        const float* Bb = Bs + b * kDBBuf + fq * kDBld + wc * 64 + fr;
+#pragma unroll
+        for (int kk = 0; kk < kDK; kk += 4) {
+            float a[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = Ab[i * 16 * kDAld + kk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = Bb[kk * kDBld + j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < kTiles) stash(b ^ 1);      // buffer b^1 was last read in iteration t-1, behind that iteration's barrier
+        __syncthreads();
+    }
+    // C/D layout: col = lane&15, row = 4*(lane>>4) + reg
+    if constexpr (!HEAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = wc * 64 + j * 16 + fr;
+                const float bias = c1[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long row = row0 + wr * 64 + i * 16 + fq * 4 + r;
+                    if (row < n) hid[row * kHid + col] = fmaxf(acc[i][j][r] + bias, 0.f);
+                }
+            }
+    } else {
+        // fused head: the staging buffers (every wave is past its last fragment read: the loop's final barrier) become the
+        // head kernel's [row][260] image of the 128 x 256 hidden tile; wave wv then runs the head's chain on rows 16 wv ..
+        float* xs = dsm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = wc * 64 + j * 16 + fr;
+            const float bias = c1[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[(wr * 64 + i * 16 + fq * 4 + r) * kChainXld + col] = fmaxf(acc[i][j][r] + bias, 0.f);
+        }
+        float w2[64];                                  // dense2 as B operands, the head kernel's packing (chain_pack_layer)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) w2[i] = w2pack[i * 64 + lane];
+        const float b2 = w2pack[64 * 64 + 16 * 64 + fr];
+        __syncthreads();
+        f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(wv * 16 + fr) * kChainXld + 4 * i + fq], w2[i], a2, 0, 0, 0);
+        f32x4 z;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[r] = a2[r] + b2;
+        chain_softmax_store(z, fr, fq, row0 + wv * 16, n, n_out, probs, labels, nullptr);
+    }
+}
+
+#ifdef MDC_ALTERNATES
+// Rounds 1-4's f32 dense1 (128 x 128 tiles, one LDS buffer, the head as its own launch), kept in the alternates build as the
+// bit-identity screen of the kernel above (MDC_DENSE1_PHASED=0 selects it, as it selects the one-barrier bf16 kernel).
+constexpr int kDN = 128, kDld = 129;
+
+__global__ __launch_bounds__(256) void vt_dense1_f32_tiles128_kernel(const float* __restrict__ feat, long n,
+                                                                     const float* __restrict__ w1p,   // [10560][256]
+                                                                     const float* __restrict__ c1,    // [256]
+                                                                     float* __restrict__ hid) {       // [n][256]
     __shared__ float As[kDK][kDld];     // As[k][row]
     __shared__ float Bs[kDK][kDld + 3]; // Bs[k][col]  (ld 132: float4 aligned rows)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -203,7 +344,6 @@ __global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restr
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int k0 = 0; k0 < kFeat; k0 += kDK) {
-        // A tile: 128 rows x 32 k -> 1024 float4, 4 per thread, stored transposed
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
@@ -212,7 +352,6 @@ __global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restr
             if (row0 + r < n) v = *reinterpret_cast<const float4*>(feat + (row0 + r) * kFeat + k0 + k4);
             As[k4 + 0][r] = v.x; As[k4 + 1][r] = v.y; As[k4 + 2][r] = v.z; As[k4 + 3][r] = v.w;
         }
-        // B tile: 32 k x 128 cols -> 1024 float4
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
@@ -236,7 +375,6 @@ __global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restr
         }
         __syncthreads();
     }
-    // C/D layout: col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -250,6 +388,7 @@ __global__ __launch_bounds__(256) void vt_dense1_f32_kernel(const float* __restr
             }
         }
 }
+#endif
 
 // Small batches: one wave = a 16-frame x 16-unit tile over the whole K, both operands straight from global memory in the
 // MFMA's lane order (A[row = lane&15][k = kk + (lane>>4)], B[k][col = lane&15], as the tiled kernel reads them from LDS):
@@ -450,14 +589,36 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
         }
         {
             ProfScope ps(m, 1, s);
-            if (n <= 2048)      // per-wave 16 x 16 tiles: 108 us at n = 256, 617 at 2,048; the 128 x 128 tiles take 1,140 us whatever the batch
-                hipLaunchKernelGGL(vt_dense1_f32_small_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s,
-                                   static_cast<const float*>(feat), (long)n, static_cast<const float*>(m->d_pack[3]),
-                                   static_cast<const float*>(m->d_pack[4]), hid);
-            else
-                hipLaunchKernelGGL(vt_dense1_f32_kernel, dim3((unsigned)((n + kDM - 1) / kDM), kHid / kDN), dim3(256), 0, s,
-                                   static_cast<const float*>(feat), (long)n, static_cast<const float*>(m->d_pack[3]),
-                                   static_cast<const float*>(m->d_pack[4]), hid);
+            const float* featf = static_cast<const float*>(feat);
+            const float* w1p = static_cast<const float*>(m->d_pack[3]);
+            const float* c1 = static_cast<const float*>(m->d_pack[4]);
+            const float* w2pack = static_cast<const float*>(m->d_pack[5]);
+            bool done = false;
+#ifdef MDC_ALTERNATES
+            if (n > 2048 && (m->alt & kAltDense1Simple)) {      // the screen: rounds 1-4's tiles, head as its own launch below
+                hipLaunchKernelGGL(vt_dense1_f32_tiles128_kernel, dim3((unsigned)((n + kDM - 1) / kDM), kHid / kDN), dim3(256), 0, s, featf, (long)n, w1p, c1, hid);
+                done = true;
+            }
+#endif
+            if (done) {
+            } else if (n <= 2048) {      // per-wave 16 x 16 tiles: 108 us at n = 256, 617 at 2,048; the work-group tiles take > 1 ms whatever the batch
+                hipLaunchKernelGGL(vt_dense1_f32_small_kernel, dim3((unsigned)((n + 15) / 16), kHid / 16), dim3(64), 0, s, featf, (long)n, w1p, c1, hid);
+            } else {
+                // the head rides in the epilogue unless a tap wants the hidden layer or the logits in HBM
+                bool fuse = tap_kind != MDC_TAP_DENSE && tap_kind != MDC_TAP_HIDDEN;
+#ifdef MDC_ALTERNATES
+                if (m->alt & kAltSeparateHead) fuse = false;
+#endif
+                const dim3 grid((unsigned)((n + kDM - 1) / kDM));
+                if (fuse) {
+                    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDense1F32Lds));
+                    hipLaunchKernelGGL(vt_dense1_f32_kernel<true>, grid, dim3(512), kDense1F32Lds, s, featf, (long)n, w1p, c1, hid, w2pack, C, probs, labels);
+                    head_done = true;
+                } else {
+                    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDense1F32Lds));
+                    hipLaunchKernelGGL(vt_dense1_f32_kernel<false>, grid, dim3(512), kDense1F32Lds, s, featf, (long)n, w1p, c1, hid, w2pack, C, probs, labels);
+                }
+            }
             MDC_HIP(hipGetLastError());
         }
     }

@@ -506,22 +506,35 @@ int vtcnn2_fp8_pack(mdc_model* m) {
     for (int o = 0; o < kC2; ++o) b2s[o] = std::ldexp(m->hb[1][o], -kFeatShift);
     if ((rc = upload(m, 2, b2s.data(), b2s.size() * sizeof(float)))) return rc;
     // dense1.  bf16 features (MDC_OPT_FP8_BF16_FEATURES): exactly the bf16 mode's (its features carry the same 2^-kFeatShift).
-    // E4M3 features: true value x 2^kf with kf from the largest conv2 output the weights allow for inputs inside the
-    // stated range -- per output channel sum_c,h,j |w2| x (conv1 bound of channel c) + |b2| -- so that nothing inside the
-    // range saturates (see the header); K in feat8_index order; the weights carry 2^-kf (a power of two: exact in bf16).
+    // E4M3 features: true value x 2^kf, K in feat8_index order; the weights carry 2^-kf (a power of two: exact in bf16).
+    // kf = floor(log2(224 / bound)), with `bound` the largest conv2 output to be REPRESENTED (anything beyond 2 x bound
+    // saturates at 448 under MODE.FP16_OVFL -- the backstop).  Round 5: the bound is no longer the worst case
+    // the weights allow (sum |w2| x conv1 bound: on the synthetic weights 46 x the largest feature N(0, 5e-3) frames produce
+    // and 29 x what a full-scale sinusoid produces -- 5 binades of E4M3's 17 unused, 4 % of the non-zero features subnormal),
+    // but either what the caller measured on a sample (mdc_set_fp8_feature_absmax), or a statistical estimate from the
+    // weights: per output channel |b2| + 12 x the rms of the conv2 sum for independent samples of rms absmax / 4 --
+    //   sqrt( sum_{c,h,j} w2^2 x (absmax^2/16 x sum_t k1[c][t]^2 + b1[c]^2) )
+    // (12 sigma: a full-scale sinusoid reaches 6.9 of these rms units, signal-shaped frames 6.2, Gaussian noise 4.4;
+    // tools/measure_bars.py records the occupancy actually reached).
     m->fp8_e4m3_features = (m->topo.reserved[0] & MDC_OPT_FP8_BF16_FEATURES) == 0;
     int kf = 0;
     if (m->fp8_e4m3_features) {
         float bound = 0.f;
-        for (int o = 0; o < kC2; ++o) {
-            double acc = std::fabs((double)m->hb[1][o]);
-            for (int ch = 0; ch < kC1; ++ch) {
-                const double c1b = (double)m->fp8_input_absmax * (std::fabs(k1[ch * 3]) + std::fabs(k1[ch * 3 + 1]) + std::fabs(k1[ch * 3 + 2])) + std::fabs(b1[ch]);
-                double wsum = 0.0;
-                for (int t = 0; t < 6; ++t) wsum += std::fabs((double)k2[((size_t)o * kC1 + ch) * 6 + t]);
-                acc += wsum * c1b;
+        if (m->fp8_feature_absmax > 0.f) {
+            bound = m->fp8_feature_absmax;
+        } else {
+            const double r2 = (double)m->fp8_input_absmax * m->fp8_input_absmax / 16.0;
+            for (int o = 0; o < kC2; ++o) {
+                double var = 0.0;
+                for (int ch = 0; ch < kC1; ++ch) {
+                    const double c1ms = r2 * ((double)k1[ch * 3] * k1[ch * 3] + (double)k1[ch * 3 + 1] * k1[ch * 3 + 1] + (double)k1[ch * 3 + 2] * k1[ch * 3 + 2])
+                                        + (double)b1[ch] * b1[ch];
+                    double w2s = 0.0;
+                    for (int t = 0; t < 6; ++t) { const double wv = k2[((size_t)o * kC1 + ch) * 6 + t]; w2s += wv * wv; }
+                    var += w2s * c1ms;
+                }
+                bound = std::fmax(bound, (float)(std::fabs((double)m->hb[1][o]) + 12.0 * std::sqrt(var)));
             }
-            bound = std::fmax(bound, (float)acc);
         }
         if (!(bound > 0.f) || !std::isfinite(bound)) { set_error("fp8: degenerate conv2 output bound"); return MDC_EINVAL; }
         kf = (int)std::floor(std::log2(224.f / bound));

@@ -53,16 +53,20 @@ class VTCNN2:
     MAX_WORKSPACES = 4
 
     def __init__(self, topology: Topology, device: Union[int, str, None] = None, dtype: str = "f32",
-                 fp8_input_absmax: Optional[float] = None, fp8_bf16_features: bool = False, _lib_variant: str = "product"):
+                 fp8_input_absmax: Optional[float] = None, fp8_bf16_features: bool = False,
+                 fp8_feature_absmax: Optional[float] = None, _lib_variant: str = "product"):
         """dtype "f32" | "bf16" (vtcnn2, deployed) | "f16" (deployed) | "fp8" (vtcnn2, deployed).  fp8_input_absmax: the largest
         |I/Q sample| the fp8 mode must represent (default 0.02, the scale of the reference's frames); larger inputs saturate.
         fp8_bf16_features (vtcnn2 at "fp8" only): MDC_OPT_FP8_BF16_FEATURES -- keep the conv2 features in bf16 as before
         ABI 4 instead of E4M3 bytes (twice the feature traffic, the old numerics).
+        fp8_feature_absmax (vtcnn2 at "fp8", E4M3 features): the largest conv2 feature to represent (mdc_set_fp8_feature_absmax);
+        None = the library's estimate from the weights; calibrate_fp8_features() measures it on a sample.
         _lib_variant: tests only (the alternates build)."""
         self.topology = topology
         self.dtype = dtype
         self.fp8_input_absmax = fp8_input_absmax
         self.fp8_bf16_features = bool(fp8_bf16_features)
+        self.fp8_feature_absmax = fp8_feature_absmax
         if self.fp8_bf16_features and not (topology.kind == "vtcnn2" and dtype == "fp8"):
             raise ValueError("fp8_bf16_features is an option of the vtcnn2 family's fp8 mode")
         self._lib_variant = _lib_variant
@@ -280,12 +284,30 @@ class VTCNN2:
                                               b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
             if self.fp8_input_absmax is not None:
                 self._check(L.mdc_set_fp8_input_absmax(h, float(self.fp8_input_absmax)))
+            if self.fp8_feature_absmax is not None and t.kind == "vtcnn2" and self.dtype == "fp8" and not self.fp8_bf16_features:
+                self._check(L.mdc_set_fp8_feature_absmax(h, float(self.fp8_feature_absmax)))
             self._check(L.mdc_finalize(h, _DTYPE[self.dtype]))
         except Exception:
             L.mdc_destroy(h)
             raise
         self._handle = h
         return h
+
+    def calibrate_fp8_features(self, X, headroom: float = 2.0) -> float:
+        """Calibration of the fp8 mode's E4M3 feature scale on a sample batch: the same weights in bf16 mode, the
+        conv tap of X, `headroom` x its largest value -> mdc_set_fp8_feature_absmax at the next (re-)finalize.  Returns the
+        value set.  X: a few hundred representative frames."""
+        if not (self.topology.kind == "vtcnn2" and self.dtype == "fp8" and not self.fp8_bf16_features):
+            raise ValueError("calibration applies to the vtcnn2 family's fp8 mode with E4M3 features")
+        probe = VTCNN2(self.topology, device=self.device_index, dtype="bf16", _lib_variant=self._lib_variant)
+        probe.set_weights(self._weights)
+        top = float(np.asarray(probe.predict(np.asarray(X, np.float32), tap="conv")).max())
+        probe._release()
+        if not top > 0.0:
+            raise ValueError("the sample produced no positive conv2 feature")
+        self.fp8_feature_absmax = headroom * top
+        self._release()
+        return self.fp8_feature_absmax
 
     def _release(self) -> None:
         if self._handle is not None:

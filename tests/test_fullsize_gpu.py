@@ -145,6 +145,19 @@ def test_dense1_kernels_agree_bit_for_bit():
     assert "bit-identical across kernels and repeats: True" in r.stdout
 
 
+def test_f32_dense1_kernels_agree_bit_for_bit():
+    """Round 5: the f32 dense1 with the full 256-unit tile and the head in its epilogue equals rounds 1-4's 128 x 128-tile
+    kernel followed by the head launch (alternates build, MDC_DENSE1_PHASED=0) and its own unfused form
+    (MDC_D1_FUSED_HEAD=0) bit for bit -- hidden layer, probabilities, labels -- on 2^16 frames, run after run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dense1.py"), "16", "2", "f32"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert "bit-identical across kernels and repeats: True" in r.stdout
+
+
 @pytest.mark.parametrize("kind,dtype", [("deployed3", "f32"), ("deployed3", "bf16"), ("deployed10", "f32"), ("vtcnn2", "bf16")])
 def test_configs3_global_batch_in_one_call(kind, dtype):
     """BASELINE configs[3]'s GLOBAL batch, 2^24 frames (+ a ragged 5), through ONE predict call on one GPU: 2^32 input floats,

@@ -26,18 +26,66 @@ def _agreement(m_ref, m, x):
     return float((a == b).float().mean())
 
 
-@pytest.mark.parametrize("dtype,floor", [("bf16", 0.998), ("fp8", 0.985)])
+# "fp8+bf16feat" = the fp8 mode with MDC_OPT_FP8_BF16_FEATURES: include/mdc.h says both feature formats hold the same floors
+MODES = [("bf16", 0.998), ("fp8", 0.985), ("fp8+bf16feat", 0.985)]
+
+
+def _vt(topo, w, mode):
+    m = VTCNN2(topo, dtype="fp8" if mode.startswith("fp8") else mode, fp8_bf16_features=mode == "fp8+bf16feat")
+    m.set_weights(w)
+    return m
+
+
+@pytest.mark.parametrize("dtype,floor", MODES)
 @pytest.mark.parametrize("classes", [11, 3])
-def test_vtcnn2_label_agreement_floor(dtype, floor, classes):
+@pytest.mark.parametrize("sigma", [5e-3, 1e-3])
+def test_vtcnn2_label_agreement_floor(dtype, floor, classes, sigma):
+    """sigma 5e-3: the bundled frames' scale.  sigma 1e-3: frames a fifth of that with the fp8 input range left at its
+    default (0.02) -- the case ADVICE r4 raised against the round-4 feature scale (worst-case bound: features pushed
+    into E4M3's subnormals); the same floor must hold."""
     topo = Topology.vtcnn2(classes)
     w = synthetic_weights(topo, seed=2016)
-    mf = VTCNN2(topo, dtype="f32")
-    mf.set_weights(w)
-    m = VTCNN2(topo, dtype=dtype)
-    m.set_weights(w)
-    x = synthetic_frames(N, seed=2016, device="cuda")
+    mf = _vt(topo, w, "f32")
+    m = _vt(topo, w, dtype)
+    x = synthetic_frames(N, seed=2016, sigma=sigma, device="cuda")
     agree = _agreement(mf, m, x)
-    assert agree >= floor, f"vtcnn2 C={classes} {dtype}: {agree:.5f} of labels equal the f32 kernels' (floor {floor})"
+    assert agree >= floor, f"vtcnn2 C={classes} {dtype} sigma={sigma}: {agree:.5f} of labels equal the f32 kernels' (floor {floor})"
+
+
+@pytest.mark.parametrize("dtype,floor", MODES)
+@pytest.mark.parametrize("kind", ["noise", "signal"])
+def test_vtcnn2_label_agreement_with_the_f64_oracle(dtype, floor, kind):
+    """the floors above are GPU against GPU (two hops to the oracle); here 4,096 frames of N(0, 5e-3)
+    noise and of signal-shaped frames (tests/signals.py) go straight against the f64 oracle's labels."""
+    from oracle import oracle_np as O
+    from tests.signals import modulated_frames
+    topo = Topology.vtcnn2(11)
+    w = synthetic_weights(topo, seed=2016)
+    x = np.asarray(synthetic_frames(4096, seed=99)) if kind == "noise" else modulated_frames(4096, seed=321)[0]
+    ref = O.forward("vtcnn2", x, w, dtype=np.float64)["labels"]
+    got = _vt(topo, w, dtype).predict_classes(x)
+    agree = float((got == ref).mean())
+    assert agree >= floor, f"vtcnn2 {dtype} {kind}: {agree:.5f} of labels equal the f64 oracle's (floor {floor})"
+    exact = float((_vt(topo, w, "f32").predict_classes(x) == ref).mean())
+    assert exact >= 0.9995, exact                       # the f32 kernels: label flips only at numerical ties
+
+
+def test_fp8_feature_calibration_on_a_sample():
+    """mdc_set_fp8_feature_absmax through VTCNN2.calibrate_fp8_features: a scale measured on 256 frames keeps the floors,
+    and a far too small one (everything saturates at 448) visibly does not -- the setter acts."""
+    topo = Topology.vtcnn2(11)
+    w = synthetic_weights(topo, seed=2016)
+    mf = _vt(topo, w, "f32")
+    x = synthetic_frames(1 << 14, seed=5, device="cuda")
+    m = _vt(topo, w, "fp8")
+    top = m.calibrate_fp8_features(synthetic_frames(256, seed=6))
+    assert 1e-4 < top < 1.0
+    assert _agreement(mf, m, x) >= 0.985
+    bad = VTCNN2(topo, dtype="fp8", fp8_feature_absmax=top * 2.0 ** -12)
+    bad.set_weights(w)
+    assert _agreement(mf, bad, x) < 0.9
+    with pytest.raises(ValueError):
+        _vt(topo, w, "bf16").calibrate_fp8_features(synthetic_frames(16, seed=6))
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
