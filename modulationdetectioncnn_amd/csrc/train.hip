@@ -142,17 +142,29 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
     for (int c = 0; c < C; ++c) gbd[c] = 0.f;
     double loss = 0.0;
 
+    // the next frame's samples and targets are loaded while this frame is computed (a wave walks its frames one at a time;
+    // the sched_barrier keeps hipcc from sinking the loads to their first use)
+    auto fetch = [&](int i, float4& xv, float (&yv)[C]) {
+        const long idx = order ? (long)order[first + i] : first + i;
+        xv = *reinterpret_cast<const float4*>(x + idx * kFrameFloats + h * kSamples + 4 * lp);
+#pragma unroll
+        for (int c = 0; c < C; ++c) yv[c] = y[idx * C + c];
+    };
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    float yn[C] = {0.f, 0.f, 0.f};
+    if (g < count) fetch(g, xn, yn);
     for (int i = g; i < count; i += G) {
         if (WLDS) asm volatile("" ::: "memory");      // keep the LDS weight reads inside the loop (hoisted, they are 150 registers again)
-        const long idx = order ? (long)order[first + i] : first + i;
-        const float4 xv = *reinterpret_cast<const float4*>(x + idx * kFrameFloats + h * kSamples + 4 * lp);
+        const float4 xv = xn;
+        float yv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) yv[c] = yn[c];
+        if (i + G < count) fetch(i + G, xn, yn);
+        __builtin_amdgcn_sched_barrier(0);
         float xprev = __shfl_up(xv.w, 1, 64);
         if (lp == 0) xprev = 0.f;                                       // ZeroPadding2D((0,1)): x[h][-1] = 0
         const float xin[S] = {xprev, xv.x, xv.y, xv.z, xv.w};           // x[h][w-1]
         const float xcu[S] = {xv.x, xv.y, xv.z, xv.w, 0.f};             // x[h][w]   (x[h][128] = 0)
-        float yv[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) yv[c] = y[idx * C + c];
         float z[C] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < S; ++s)

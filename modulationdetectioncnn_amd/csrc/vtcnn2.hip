@@ -189,13 +189,14 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
 //    launch): the hidden layer neither goes to HBM nor comes back, and the f32 batch path is two launches, not three.
 // 8 waves (2 x 4), each 64 x 64 = 4 x 4 MFMA tiles, BK = 32, two LDS buffers filled through registers one K-tile ahead
 // (global loads issued before a tile's MFMAs, LDS writes after them: one barrier per K-tile).  LDS images chosen for the
-// fragment reads: A as [row][36] (a lane reads A[row = lane&15][k = kk + (lane>>4)]: bank 36 row + k, all 64 distinct),
-// B as [k][272] (bank 16 (lane>>4) + (lane&15) + const: all 64 distinct); both are written with 16-byte stores.
+// fragment reads (ds_read_b32 / ds_read2_b32: two groups of 32 lanes over 32 banks): A as [row][34] -- a lane reads
+// A[row = lane&15][k = kk + (lane>>4)], bank 2 row + k: the 32 lanes of a group on 32 banks --, B as [k][272] -- bank
+// 16 (lane>>4) + (lane&15): likewise.  A rows are 136 B (8-byte aligned): written with two ds_write_b64, B with ds_write_b128.
 // The per-element accumulation order (K-tiles ascending, k-steps of 4 ascending, one MFMA chain per output tile) is that
 // of the old kernel and of vt_dense1_f32_small_kernel: bit-identical hidden layer (tests/test_fullsize_gpu.py).
 // ------------------------------------------------------------------------------------
 constexpr int kDM = 128, kDK = 32;
-constexpr int kDAld = 36, kDBld = 272;
+constexpr int kDAld = 34, kDBld = 272;
 constexpr int kDABuf = kDM * kDAld, kDBBuf = kDK * kDBld;                    // floats per buffer
 constexpr size_t kDense1F32Lds = (size_t)kDM * kChainXld * sizeof(float);   // the epilogue's [128][260] image (133,120 B) > 2 x (A + B) = 106,496 B
 static_assert(kDense1F32Lds >= 2 * (kDABuf + kDBBuf) * sizeof(float), "the staging buffers must fit under the epilogue image");
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
                                                             const float* __restrict__ w2pack, int n_out,
                                                             float* __restrict__ probs, int* __restrict__ labels) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    float* As = dsm;                    // [2][128][36]
+    float* As = dsm;                    // [2][128][34]
     float* Bs = dsm + 2 * kDABuf;       // [2][32][272]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 2, wc = wv & 3;
@@ -232,11 +233,10 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
     const float* bp = w1p + (size_t)bk0 * kHid + bc4;
     auto fetch = [&](int k0) {
         // (the address is always valid -- clamped to row 0 --, the VALUE is selected: `ok ? *p : zero` made hipcc select
-        // between two addresses and park the zeros in scratch)
+        // between two addresses and park the zeros in scratch
+        // ... and selected in stash(), a K-tile later: selecting here would wait for the load right behind its issue)
         ga0 = *reinterpret_cast<const float4*>(ap0 + k0);
         ga1 = *reinterpret_cast<const float4*>(ap1 + k0);
-        if (!aok0) ga0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!aok1) ga1 = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* b = bp + (size_t)k0 * kHid;
         gb0 = *reinterpret_cast<const float4*>(b);
         gb1 = *reinterpret_cast<const float4*>(b + 8 * kHid);
@@ -245,8 +245,11 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
     };
     auto stash = [&](int b) {
         float* a = As + b * kDABuf + ar0 * kDAld + ak4;
-        *reinterpret_cast<float4*>(a) = ga0;
-        *reinterpret_cast<float4*>(a + 64 * kDAld) = ga1;
+        const float4 v0 = aok0 ? ga0 : make_float4(0.f, 0.f, 0.f, 0.f), v1 = aok1 ? ga1 : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float2*>(a) = make_float2(v0.x, v0.y);
+        *reinterpret_cast<float2*>(a + 2) = make_float2(v0.z, v0.w);
+        *reinterpret_cast<float2*>(a + 64 * kDAld) = make_float2(v1.x, v1.y);
+        *reinterpret_cast<float2*>(a + 64 * kDAld + 2) = make_float2(v1.z, v1.w);
         float* d = Bs + b * kDBBuf + bk0 * kDBld + bc4;
         *reinterpret_cast<float4*>(d) = gb0;
         *reinterpret_cast<float4*>(d + 8 * kDBld) = gb1;
@@ -260,6 +263,9 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
     for (int t = 0; t < kTiles; ++t) {
         const int b = t & 1;
         if (t + 1 < kTiles) fetch((t + 1) * kDK);
+        // the loads above are ISSUED here, one K-tile ahead of their use: left to itself hipcc sinks them behind the MFMAs and
+        // waits for them at once (the whole global-load latency exposed at the end of every K-tile: 3.30 ms per 65,536 frames)
+        __builtin_amdgcn_sched_barrier(0);
         const float* Ab = As + b * kDABuf + (wr * 64 + fr) * kDAld + fq;
         const float* Bb = Bs + b * kDBBuf + fq * kDBld + wc * 64 + fr;
 #pragma unroll
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < kTiles) stash(b ^ 1);      // buffer b^1 was last read in iteration t-1, behind that iteration's barrier
         __syncthreads();
     }

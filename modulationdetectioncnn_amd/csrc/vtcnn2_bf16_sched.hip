@@ -145,8 +145,14 @@ __device__ __forceinline__ void sch_step(SchedState& st, int v, int q, unsigned 
 #define LD() do { if (kC1 && ABL != 11) { if (kLoadEven) sch_load_even<LSLOT>(st, load_addr); else if (kLoadOdd) sch_load_odd(st, load_addr); } } while (0)
     // the barrier's lgkmcnt(0) covers the ds_writes of a2, issued >= 14 MFMAs earlier.  a2 stays allocated until
     // here (ds_write / XDL hazard above): no MFMA issued before this point can have been given its registers
+    // (MDC_F8_PROBE_HALF_BARRIER, round 5: timing-only probe of a two-step rendezvous -- the barrier on even steps only; results wrong)
+#ifdef MDC_F8_PROBE_HALF_BARRIER
+    constexpr bool kHalfBarrierSkip = (V12 & 1) == 1;
+#else
+    constexpr bool kHalfBarrierSkip = false;
+#endif
 #define HANDOFF() do { \
-        if (ABL == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (ABL == 1 || kHalfBarrierSkip) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         else if (kExch) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
     sch_wait_lds(st);      // partial(v-1) and any operand words: read during T0 of the previous step

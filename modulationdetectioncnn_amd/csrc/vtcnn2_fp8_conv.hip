@@ -192,9 +192,17 @@ __device__ __forceinline__ void f8_step(Fp8State& st, int v, int q, typename std
 #define CV(K) do { if (!LAST) f8_cvt<PN, K>(st); } while (0)
 #define RD(R) sch_red_load1<PAR, R>(st)
 #define LD() do { if (kLoadEven) sch_load_even<LSLOT>(st, load_addr); else if (kLoadOdd) sch_load_odd(st, load_addr); } while (0)
+#ifdef MDC_F8_PROBE_HALF_BARRIER      // timing-only probe (round 5; results wrong by construction): the four-wave rendezvous on EVEN
+    // steps only -- what a two-step rendezvous (four partial buffers, a step pattern of period 24) could buy at most
+#define HANDOFF() do { \
+        if constexpr ((V12 & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
+#else
 #define HANDOFF() do { \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         asm volatile("" ::"a"(a2[0]), "a"(a2[1]), "a"(a2[2]), "a"(a2[3]), "a"(a2[4])); } while (0)
+#endif
     sch_wait_lds(st);
     // 54 VALU per step (rounds 1-2: 73) spread evenly over the 17 gaps: three per gap, four in three of them (a 32-cycle gap
     // takes two VALU for free, a third costs 4 cycles, a fourth 8 more: tools/microbench/mfma_gap.hip).
