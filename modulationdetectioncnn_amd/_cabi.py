@@ -59,6 +59,14 @@ def lib(variant: str = "product") -> C.CDLL:
         raise RuntimeError(
             f"{path} is missing: build it with `python -m modulationdetectioncnn_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    # torch FIRST: its wheel bundles its own libamdhip64.so, libmdc.so names the system's as DT_NEEDED, and whichever HIP runtime a
+    # process loads first serves both (same soname).  Loaded the other way round the process ends up with TWO runtimes, and
+    # the one under libmdc.so then finds no device (`mdc_create`: MDC_ENODEV) -- measured on the GPU box, round 5.  The Python
+    # mirror hands torch tensors to the library anyway; a caller without torch (examples/c_client.c) has one runtime by construction.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
     L.mdc_abi_version.restype = i32

@@ -18,7 +18,8 @@
 //                    ends with the same bits).  Each wave writes ONE partial gradient vector; the shuffle of fit() is an
 //                    index array (`order`), frames are never moved.
 //   mdc_train_adam   sums the G partials in a fixed order (the result depends on (count, G) only -- no float atomics, so
-//                    a step is reproducible bit for bit), scales by 1/count (gradient of the MEAN loss), and applies
+//                    a step is reproducible bit for bit; G = count / 2, or / 4 for the 10-filter net, at most 1,024),
+//                    scales by 1/count (gradient of the MEAN loss), and applies
 //                    TensorFlow 2.4's Adam: alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1); v += (g*g-v)(1-b2);
 //                    w -= m*alpha/(sqrt(v)+eps).  t lives on the device (incremented by the gradient kernel), so a
 //                    captured hipGraph of an epoch replays correctly.
@@ -371,25 +372,41 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
     if (lane == 0 && bump_iter && g == 0) st->iterations += 1;
 }
 
-// ---- fixed-order reduction of the partials + TensorFlow 2.4's Adam.  Block = 64 parameters x 4 slices of the G partials.
+// ---- fixed-order reduction of the partials + TensorFlow 2.4's Adam.  Block = 64 parameters x 16 slices of the G partials: a
+// thread's <= 64 loads are independent (unrolled 16 at a time: the first version's one-load-at-a-time chain of 64 took 30 us,
+// twice the gradient kernel), the sums are taken in a fixed order -- slice by slice, then the 16 slices in order.
 // mode: 0 = losses only (evaluation), 1 = gradient stored, 2 = gradient stored and applied
-__global__ __launch_bounds__(256) void train_adam_kernel(const float* __restrict__ partials, const double* __restrict__ loss_partials, int G,
-                                                        int P, int count, int mode, float lr, float beta1, float beta2, float eps,
-                                                        float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
-                                                        float* __restrict__ grad, TrainState* __restrict__ st) {
-    __shared__ float part[4][64];
+constexpr int kRedSlices = 16;
+
+__global__ __launch_bounds__(1024) void train_adam_kernel(const float* __restrict__ partials, const double* __restrict__ loss_partials, int G,
+                                                         int P, int count, int mode, float lr, float beta1, float beta2, float eps,
+                                                         float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ grad, TrainState* __restrict__ st) {
+    __shared__ float part[kRedSlices][64];
+    __shared__ double lpart[1024];
     const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
     if (mode != 0) {
         float acc = 0.f;
         if (i < P) {
-            const int per = (G + 3) / 4, lo = slice * per, hi = min(G, lo + per);
-            for (int w = lo; w < hi; ++w) acc += partials[(size_t)w * P + i];
+            const int per = (G + kRedSlices - 1) / kRedSlices, lo = slice * per, hi = min(G, lo + per);
+            const float* src = partials + (size_t)lo * P + i;
+            int w = lo;
+            for (; w + 16 <= hi; w += 16, src += (size_t)16 * P) {
+                float t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = src[(size_t)u * P];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += t[u];
+            }
+            for (; w < hi; ++w, src += P) acc += *src;
         }
         part[slice][col] = acc;
         __syncthreads();
         if (slice == 0 && i < P) {
-            const float gsum = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+            float gsum = part[0][col];
+#pragma unroll
+            for (int sl = 1; sl < kRedSlices; ++sl) gsum += part[sl][col];
             const float gmean = gsum / (float)count;
             grad[i] = gmean;
             if (mode == 2) {
@@ -403,11 +420,17 @@ __global__ __launch_bounds__(256) void train_adam_kernel(const float* __restrict
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < G; ++w) s += loss_partials[w];
-        if (mode == 0) { st->eval_loss += s; st->eval_frames += count; }
-        else { st->train_loss += s; st->train_frames += count; }
+    if (blockIdx.x == 0) {      // the batch's summed loss: G <= 1,024 partials, one per thread, a fixed tree
+        lpart[threadIdx.x] = (int)threadIdx.x < G ? loss_partials[threadIdx.x] : 0.0;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) lpart[threadIdx.x] += lpart[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (mode == 0) { st->eval_loss += lpart[0]; st->eval_frames += count; }
+            else { st->train_loss += lpart[0]; st->train_frames += count; }
+        }
     }
 }
 
@@ -441,18 +464,20 @@ int trainer_layout(mdc_trainer* t) {
     return MDC_OK;
 }
 
-int waves_for(int64_t count, bool grad) {
-    // a wave per 4 frames while the batch is small (1,024 frames -> 256 waves, one per CU); evaluation of a large set
-    // wants the memory system busy instead: up to kMaxWaves either way
-    int64_t g = (count + 3) / 4;
+int waves_for(const mdc_trainer* t, int64_t count) {
+    // A wave walks its frames one at a time, so the batch's latency is (frames per wave) x (one frame): two frames per wave
+    // for the nets whose partial vector is small (T1: 2,334 floats, T4: 2,935 -- 512 waves for the reference's 1,024-frame
+    // batch), four for the 10-filter net (7,773 floats per partial: the reduction's traffic would double); never more than
+    // kMaxWaves (evaluation of a large set then walks count / 1,024 frames per wave with every CU busy).
+    const int per_wave = (t->topo.kind == MDC_KIND_DEPLOYED && t->topo.filters == 10) ? 4 : 2;
+    int64_t g = (count + per_wave - 1) / per_wave;
     if (g < 1) g = 1;
     if (g > kMaxWaves) g = kMaxWaves;
-    (void)grad;
     return (int)g;
 }
 
 int launch_batch(mdc_trainer* t, const float* x, const float* y, const int32_t* order, int64_t first, int64_t count, int mode, hipStream_t s) {
-    const int G = waves_for(count, mode != 0);
+    const int G = waves_for(t, count);
     auto* st = static_cast<TrainState*>(t->d_state);
     const int bump = mode == 2 ? 1 : 0;
     const int cnt = (int)count;
@@ -473,7 +498,7 @@ int launch_batch(mdc_trainer* t, const float* x, const float* y, const int32_t* 
     MDC_HIP(hipGetLastError());
     const int P = (int)t->P;
     const int blocks = mode == 0 ? 1 : (P + 63) / 64;
-    hipLaunchKernelGGL(train_adam_kernel, dim3(blocks), dim3(256), 0, s, t->d_partials, t->d_loss_partials, G, P, cnt, mode, t->lr, t->beta1, t->beta2,
+    hipLaunchKernelGGL(train_adam_kernel, dim3(blocks), dim3(1024), 0, s, t->d_partials, t->d_loss_partials, G, P, cnt, mode, t->lr, t->beta1, t->beta2,
                        t->eps, t->d_params, t->d_m, t->d_v, t->d_grad, st);
     MDC_HIP(hipGetLastError());
     return MDC_OK;

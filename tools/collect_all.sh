@@ -4,7 +4,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1150 -- 'bash tools/collect_all.sh r02'
 # then here:  bash tools/collect_all.sh r02 summarize
 set -e -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 if [ "$2" = "summarize" ]; then
     python3 tools/summarize_profiles.py $TAG > /dev/null
     python3 tools/summarize_dep_counters.py $TAG > /dev/null

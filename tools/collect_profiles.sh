@@ -7,7 +7,7 @@
 # (gpurun_out/ is scratch): summarize_profiles.py stamps the round on what it copies into profiles/.
 set -e -o pipefail
 R=$PWD
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 P="--output-format csv"
 rm -rf $R/gpurun_out/prof_${TAG}_bench $R/gpurun_out/prof_${TAG}_bench_extras $R/gpurun_out/pmc_*_vt $R/gpurun_out/pmc_*_dep $R/gpurun_out/prof_${TAG}_dep
@@ -42,3 +42,7 @@ rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_dep -- $D > $R/
 rocprofv3 --pmc FETCH_SIZE $P -d $R/gpurun_out/pmc_fetch_dep -- $D > $R/gpurun_out/pmc_fetch_dep.log 2>&1
 rocprofv3 --pmc WRITE_SIZE $P -d $R/gpurun_out/pmc_write_dep -- $D > $R/gpurun_out/pmc_write_dep.log 2>&1
 echo "deployed done"
+# the training step (round 5): kernel times at the reference's batch geometry
+rm -rf $R/gpurun_out/prof_${TAG}_train
+rocprofv3 --kernel-trace --stats $P -d $R/gpurun_out/prof_${TAG}_train -- python3 $R/tools/prof_train.py > $R/gpurun_out/prof_${TAG}_train.log 2>&1
+echo "training done"
