@@ -234,7 +234,10 @@ constexpr int kUnitBytes = 128 * 128;      // 128 rows x 64 bf16
 // the counted waits become vmcnt(2) / (3) / (4) / (3) (last tile: (1) / (0)): phase p still retires exactly the unit the
 // next phase reads.  The raw fragments (ra) are converted once, right after their wait: a1 in phase 2 before its first
 // quadrant, the next tile's a0 at the end of phase 3 under that phase's MFMAs.
-template <int ABL, bool HEAD = false, bool F8 = false>   // ABL 0 = product; 1 = timing-only probe: every work-group streams the same A rows (L2 hits)
+// ABL 0 = product; timing-only probes (results wrong by construction; tools/ablate_dense1.py): 1 = every work-group streams the same A
+// rows (L2 hits); round 5: 2 = the WEIGHT units staged on even K-tiles only (half the weight LDS-DMA: the most a 512-row tile could
+// save on that side), 3 = the fragment reads on even K-tiles only (half the LDS read volume: the most 32x32x16 quadrants could save)
+template <int ABL, bool HEAD = false, bool F8 = false>
 __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsigned short* __restrict__ feat, long n,
                                                                     const unsigned short* __restrict__ w1t,   // [165][256][64]
                                                                     const float* __restrict__ c1, float* __restrict__ hid,
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         src8[1] = f8 + g3 * (long)kFeat + sw;
     }
     auto stage_unit = [&](int t, int unit, int b) {
+        if (ABL == 2 && (unit == 1 || unit == 2) && (t & 1)) return;
         unsigned char* dst = smem + ((size_t)b * 4 + unit) * kUnitBytes + (wv * 2) * 1024;
         if constexpr (F8) {
             if (unit == 0 || unit == 3) {      // E4M3 feature rows: 64 B per row and K-tile, one piece per wave.  NOT non-temporal:
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         ra_lane[1] = ra_lane[0] ^ 32u;
     }
     auto read_a = [&](bf16x8 (&a)[4][2], int unit, int b) {
+        if (ABL == 3 && b == 1) return;
         const unsigned char* base = smem + ((size_t)b * 4 + unit) * kUnitBytes;
         if constexpr (F8) {
             const unsigned bl = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)const_cast<unsigned char*>(base);
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(512) void vt_dense1_bf16_phased_kernel(const unsign
         }
     };
     auto read_b = [&](bf16x8 (&bq)[2][2], int unit, int b) {
+        if (ABL == 3 && b == 1) return;
         const unsigned char* base = smem + ((size_t)b * 4 + unit) * kUnitBytes;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -696,12 +702,16 @@ int vtcnn2_bf16_dense1(const mdc_model* m, const void* feat, int64_t n, float* h
 #endif
 #ifdef MDC_ABLATIONS
     static const int abl = getenv("MDC_ABLATE_D1") ? atoi(getenv("MDC_ABLATE_D1")) : 0;
-    if (abl == 11) {      // the phased kernel with its A rows from L2
-        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds));
-        hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<1>, grid, dim3(512), kDenseBf16Lds, s, f, (long)n, w1t, c1, hid);
-        MDC_HIP(hipGetLastError());
-        return MDC_OK;
-    }
+#define MDC_LAUNCH_PROBE(A) do { \
+        MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_bf16_phased_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseBf16Lds)); \
+        hipLaunchKernelGGL(vt_dense1_bf16_phased_kernel<A>, grid, dim3(512), kDenseBf16Lds, s, f, (long)n, w1t, c1, hid); \
+        MDC_HIP(hipGetLastError()); \
+        return MDC_OK; } while (0)
+    if (!f8 && abl == 10) MDC_LAUNCH_PROBE(0);      // the phased kernel, unfused (the probes' own baseline)
+    if (!f8 && abl == 11) MDC_LAUNCH_PROBE(1);      // ... with its A rows from L2
+    if (!f8 && abl == 12) MDC_LAUNCH_PROBE(2);      // ... with the weight units staged on even K-tiles only
+    if (!f8 && abl == 13) MDC_LAUNCH_PROBE(3);      // ... with the fragment reads on even K-tiles only
+#undef MDC_LAUNCH_PROBE
     if (abl >= 1 && abl <= 3) {
         switch (abl) { case 1: MDC_LAUNCH_D1(1); break; case 2: MDC_LAUNCH_D1(2); break; default: MDC_LAUNCH_D1(3); }
         MDC_HIP(hipGetLastError());
