@@ -313,3 +313,46 @@ def test_refusals():
     m = VTCNN2.synthetic(topo, device=0)
     with pytest.raises(ValueError):
         m.compile(loss="mse")
+
+
+def test_example_train_like_cnn_py(tmp_path):
+    """examples/train_like_cnn_py.py: cnn.py:42-153 call for call -- split, compile, fit with the two callbacks, load_weights
+    of the checkpoint, evaluate -- and the score it prints is the checkpoint's val_loss."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_like_cnn_py", os.path.join(root, "examples", "train_like_cnn_py.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    ck = str(tmp_path / "convmodrecnets_CNN2_0.5.wts.h5")
+    model, history, score, (X_test, y_test) = ex.main([ck, "--epochs", "8", "--lr", "0.01"])
+    assert X_test.shape == (8100, 2, 128)                                   # 70 / 30 of 27,000: CNN.ipynb cell 5's 18,900 training frames
+    assert abs(score - min(history.history["val_loss"])) <= 1e-5 * score
+    assert history.history["loss"][-1] < history.history["loss"][0]
+    assert model.accuracy(X_test, y_test) > 0.45
+    assert load_keras_h5(ck).keras_version == "2.4.0"
+
+
+@pytest.mark.parametrize("kind,topo", CASES[:3], ids=IDS[:3])
+def test_gradient_is_additive_over_the_batch_at_full_size(kind, topo):
+    """A size-independent property at a size the oracle would take minutes for: the gradient of the mean loss over 2^16 frames
+    (1,024 waves, 64 or 32 frames each) is the frame-weighted mean of the gradients of its two unequal parts, and so is the loss."""
+    n, cut = 1 << 16, 20001
+    w = synthetic_weights(topo, seed=13, bias_scale=0.05)
+    x, y = _data(topo, n, seed=99)
+    tr = Trainer(topo, w, device=0)
+    xd, yd = tr._frames(x), tr._targets(y, n)
+
+    def part(first, count):
+        tr.read(reset=True)
+        tr.train_batch(xd, yd, None, first, count, apply=False)
+        r = tr.read(reset=True)
+        return r["train_loss_sum"], tr.gradients()
+
+    l_all, g_all = part(0, n)
+    l_a, g_a = part(0, cut)
+    l_b, g_b = part(cut, n - cut)
+    assert abs(l_all - (l_a + l_b)) <= 1e-9 * abs(l_all)                       # f64 sums of the same per-frame f32 losses
+    for (ka, ba), (kb, bb), (k, b) in zip(g_a, g_b, g_all):
+        mix_k = (ka.astype(np.float64) * cut + kb.astype(np.float64) * (n - cut)) / n
+        mix_b = (ba.astype(np.float64) * cut + bb.astype(np.float64) * (n - cut)) / n
+        assert _rel(k, mix_k) <= 2e-5 and _rel(b, mix_b) <= 2e-5, (_rel(k, mix_k), _rel(b, mix_b))
