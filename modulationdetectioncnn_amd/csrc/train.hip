@@ -11,11 +11,11 @@
 //                    the softmax rows (row / sum, clip to [1e-7, 1-1e-7], -sum y log q; the clip blocks the gradient
 //                    outside the interval, the ReLUs where the pre-activation is <= 0), backward with the activations
 //                    RECOMPUTED from the frame still in registers -- nothing but the 1 KiB frame is read per sample and
-//                    nothing per-sample is written.  A lane owns a fixed set of weights (deployed: 4 (+1) conv
-//                    positions x F filters x 3 classes of the dense kernel; cnn.py: 2 of the 128 input channels x 2 taps x
-//                    F filters of the conv kernel) for the whole slice, so their gradients accumulate in its registers and
-//                    only the per-frame reductions (3 class sums / 3F conv sums) cross lanes (xor butterfly: every lane
-//                    ends with the same bits).  Each wave writes ONE partial gradient vector; the shuffle of fit() is an
+//                    nothing per-sample is written.  Deployed nets: a lane owns a fixed set of weights (4 (+1) conv
+//                    positions x F filters x 3 classes of the dense kernel) for the whole slice, so their gradients
+//                    accumulate in its registers and only the per-frame reductions (3 class sums) cross lanes (xor
+//                    butterfly: every lane ends with the same bits).  cnn.py's net: 16-frame tiles on the f32 MFMA
+//                    (see train_cnnpy_kernel).  Each wave writes ONE partial gradient vector; the shuffle of fit() is an
 //                    index array (`order`), frames are never moved.
 //   mdc_train_adam   sums the G partials in a fixed order (the result depends on (count, G) only -- no float atomics, so
 //                    a step is reproducible bit for bit; G = count / 2, or / 4 for the 10-filter net, at most 1,024),
@@ -25,11 +25,12 @@
 //                    captured hipGraph of an epoch replays correctly.
 // The batch of the reference (1,024 frames x 2,334 parameters) is launch-latency bound on this chip; that is why a step
 // is two launches and an epoch needs no host round trip but the final read of the loss.
-#include "mdc_internal.h"
+#include "dense_chain_common.h"      // mdc_internal.h, f32x4, row_allreduce (the 16-lane DPP butterflies of the softmax head)
 
 #include <cstddef>
 #include <cstring>
 #include <new>
+#include <vector>
 
 struct mdc_trainer {
     mdc_topology topo{};
@@ -45,7 +46,9 @@ struct mdc_trainer {
     float* d_m = nullptr;        // [P] Adam first moment
     float* d_v = nullptr;        // [P] Adam second moment
     float* d_grad = nullptr;     // [P] gradient of the last batch's mean loss
-    float* d_partials = nullptr; // [kMaxWaves][P]
+    float* d_partials = nullptr; // [kMaxWaves][Pint]
+    size_t Pint = 0;             // floats per partial gradient vector: P for the deployed nets, the MFMA kernel's internal layout for cnn.py's
+    int* d_map = nullptr;        // [P][3]: the (up to three) entries of a partial vector that sum to parameter i (-1 = none)
     double* d_loss_partials = nullptr;   // [kMaxWaves]
     void* d_state = nullptr;     // TrainState
 };
@@ -223,8 +226,23 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
     }
 }
 
-// ---- cnn.py's literal net (cnn.py:104-112 as TensorFlow builds it: H=1, W=2, C=128): lane owns input channels lane, lane+64
+// ---- cnn.py's literal net (cnn.py:104-112 as TensorFlow builds it: H=1, W=2, C=128) on v_mfma_f32_16x16x4_f32, 16 frames at a time.
+// pad + Conv2D(F,(1,2)) over (1, 2+2, 128) is a LINEAR map of the frame's 256 floats to 3F values (csrc/cnnpy.hip folds it the
+// same way): pre = x . Mc,  Mc[c][w=0] = K1[c], Mc[c][w=1] = K0[c] (I half), Mc[128+c][w=1] = K1[c], Mc[128+c][w=2] = K0[c].
+// Everything is a small GEMM with M = the 16 frames of a tile:
+//   forward   PRE[16][32] = X[16][256] Mc  (128 MFMAs) -> ReLU -> Z1 = A1 W1 (8) -> ReLU -> LG = H W2 (4) -> softmax / loss
+//   backward  dW2 += H^T dLG, dW1 += A1^T dZ1, dMc += X^T dPRE: sums over FRAMES, i.e. K = the tile's 16 frames.  With k-step i
+//             carrying frames 4 (lane>>4) + i, the MFMA's A and B operands are exactly registers i of the C/D-layout results
+//             (lane = column, rows 4 (lane>>4) + r): no transposition, no LDS.  dH = dLG W2^T and dA1 = dZ1 W1^T need the
+//             row-major form of a C/D result: a 2 KiB LDS round trip each, as in the forward chain (dense_chain.hip).
+// A wave keeps Mc (128 registers as B operands), the small layers' operands and the gradient accumulators (dMc: 128
+// registers) for its whole slice of the batch and writes ONE partial vector in an internal layout ([256][32] for dMc, 16-wide
+// small layers); train_adam_kernel folds it into Keras' layout through an index map (each conv weight is the sum of two dMc
+// entries, each conv bias of three column sums).  A 1,024-frame batch is 64 waves x one tile.
 constexpr int kTF = 10, kTD = 16, kTC = 16;      // bounds of MDC_KIND_CNNPY (mdc_create): filters <= 10, hidden <= 16, classes <= 16
+constexpr int kT4Mc = 0, kT4Cb = 256 * 32, kT4W1 = kT4Cb + 32, kT4B1 = kT4W1 + 32 * 16, kT4W2 = kT4B1 + 16, kT4B2 = kT4W2 + 16 * 16,
+              kT4Pint = kT4B2 + 16;              // 9,024 floats per partial
+constexpr int kT4Xld = kChainXld, kT4Yld = 36;
 
 template <bool GRAD>
 __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ order,
@@ -232,144 +250,188 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
                                                         float* __restrict__ partials, double* __restrict__ loss_partials,
                                                         TrainState* __restrict__ st, int bump_iter) {
     const int A = 3 * F;
-    const int offCb = 256 * F, offW1 = offCb + F, offB1 = offW1 + A * D, offW2 = offB1 + D, offB2 = offW2 + D * C, P = offB2 + C;
-    __shared__ float sW1[3 * kTF * kTD], sW2[kTD * kTC], sB1[kTD], sB2[kTC], sCb[kTF];
-    __shared__ float sA[3 * kTF], sPre[3 * kTF], sH[kTD], sZ1[kTD], sLg[kTC], sGlg[kTC], sGz1[kTD], sGa[3 * kTF];
-    const int lane = threadIdx.x, G = gridDim.x, g = blockIdx.x;
-    for (int i = lane; i < A * D; i += 64) sW1[i] = params[offW1 + i];
-    for (int i = lane; i < D * C; i += 64) sW2[i] = params[offW2 + i];
-    if (lane < D) sB1[lane] = params[offB1 + lane];
-    if (lane < C) sB2[lane] = params[offB2 + lane];
-    if (lane < F) sCb[lane] = params[offCb + lane];
-    // conv kernel HWIO (1,2,128,F): ((kw*128 + c)*F + f)
-    float K[2][2][kTF], gK[2][2][kTF];      // [channel slot][kw][f]
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int kw = 0; kw < 2; ++kw)
-#pragma unroll
-            for (int f = 0; f < kTF; ++f) {
-                K[u][kw][f] = f < F ? params[(kw * 128 + lane + 64 * u) * F + f] : 0.f;
-                gK[u][kw][f] = 0.f;
-            }
-    float gW1[8], gW2[4], gB1 = 0.f, gB2 = 0.f, gCb = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) gW1[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gW2[i] = 0.f;
-    double loss = 0.0;
-    __syncthreads();
+    const int offCb = 256 * F, offW1 = offCb + F, offB1 = offW1 + A * D, offW2 = offB1 + D, offB2 = offW2 + D * C;
+    __shared__ __attribute__((aligned(16))) float xs[16 * kT4Xld];
+    __shared__ float ys[16 * kT4Yld];
+    __shared__ double sloss[4];
+    const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
+    const int G = gridDim.x;
 
-    for (int i = g; i < count; i += G) {
-        const long idx = order ? (long)order[first + i] : first + i;
-        const float* fr = x + idx * kFrameFloats;
-        const float xi[2] = {fr[lane], fr[lane + 64]}, xq[2] = {fr[kSamples + lane], fr[kSamples + lane + 64]};
-        // padded width 4: [0, I, Q, 0]; conv output w: K[kw=0] . xp[w] + K[kw=1] . xp[w+1]
-        float pre[3][kTF];
+    // ---- operands (B[k = 4i + g][col = fr] per k-step i), rebuilt from the master weights at every launch
+    float Mw[2][64], cbv[2];
 #pragma unroll
-        for (int f = 0; f < kTF; ++f) {
-            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    for (int jt = 0; jt < 2; ++jt) {
+        const int j = 16 * jt + fr, w = j / F, f = j - w * F;
+        const bool col_ok = j < A;
+        cbv[jt] = col_ok ? params[offCb + f] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                p0 = fmaf(K[u][1][f], xi[u], p0);
-                p1 = fmaf(K[u][0][f], xi[u], fmaf(K[u][1][f], xq[u], p1));
-                p2 = fmaf(K[u][0][f], xq[u], p2);
+        for (int i = 0; i < 64; ++i) {
+            const int k = 4 * i + g, c = k & 127;
+            // I half (k < 128): w 0 -> tap 1, w 1 -> tap 0; Q half: w 1 -> tap 1, w 2 -> tap 0
+            const int kw = k < 128 ? (w == 0 ? 1 : w == 1 ? 0 : -1) : (w == 1 ? 1 : w == 2 ? 0 : -1);
+            Mw[jt][i] = (col_ok && kw >= 0) ? params[(kw * 128 + c) * F + f] : 0.f;
+        }
+    }
+    float W1b[8], W2b[4], W2t[4], W1t[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int j = 4 * i + g; W1b[i] = (j < A && fr < D) ? params[offW1 + j * D + fr] : 0.f; }      // Z1 = A1 W1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 4 * i + g;
+        W2b[i] = (k < D && fr < C) ? params[offW2 + k * C + fr] : 0.f;            // LG = H W2:      B[k = d][col = c]
+        W2t[i] = (k < C && fr < D) ? params[offW2 + fr * C + k] : 0.f;            // dH = dLG W2^T:  B[k = c][col = d]
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) { const int j = 16 * jt + fr; W1t[jt][i] = (j < A && k < D) ? params[offW1 + j * D + k] : 0.f; }      // dA1 = dZ1 W1^T: B[k = d][col = j]
+    }
+    const float b1v = fr < D ? params[offB1 + fr] : 0.f, b2v = fr < C ? params[offB2 + fr] : 0.f;
+    const bool cls = fr < C;
+
+    f32x4 dM[GRAD ? 16 : 1][2], dW1a[2], dW2a;
+    float gcb[2] = {0.f, 0.f}, gb1 = 0.f, gb2 = 0.f;
+    if (GRAD) {
+#pragma unroll
+        for (int T = 0; T < 16; ++T) { dM[T][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dM[T][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    dW1a[0] = dW1a[1] = dW2a = f32x4{0.f, 0.f, 0.f, 0.f};
+    double loss = 0.0;
+
+    const int ntiles = (count + 15) >> 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+        const int f0 = tile << 4;
+        // ---- stage the tile's 16 frames (1 KiB each, one float4 per lane), zeros past the end of the batch
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f0 + r < count) {
+                const long idx = order ? (long)order[first + f0 + r] : first + f0 + r;
+                v = reinterpret_cast<const float4*>(x + idx * kFrameFloats)[lane];
             }
-            if (f < F) {      // (uniform)
-                pre[0][f] = wave_allsum(p0) + sCb[f];
-                pre[1][f] = wave_allsum(p1) + sCb[f];
-                pre[2][f] = wave_allsum(p2) + sCb[f];
-            } else {
-                pre[0][f] = pre[1][f] = pre[2][f] = 0.f;
+            *reinterpret_cast<float4*>(xs + r * kT4Xld + 4 * lane) = v;
+        }
+        // targets in the C/D layout: lane (class fr, rows 4g + r); zero rows past the end contribute nothing anywhere below
+        float yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int fi = f0 + 4 * g + r;
+            yv[r] = 0.f;
+            if (cls && fi < count) { const long idx = order ? (long)order[first + fi] : first + fi; yv[r] = y[idx * C + fr]; }
+        }
+        __syncthreads();
+        // ---- forward
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float a = xs[fr * kT4Xld + 4 * i + g];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Mw[0][i], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Mw[1][i], acc[1], 0, 0, 0);
+        }
+        f32x4 pre[2], a1[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pre[jt][r] = acc[jt][r] + cbv[jt];
+                a1[jt][r] = fmaxf(pre[jt][r], 0.f);
+                ys[(4 * g + r) * kT4Yld + 16 * jt + fr] = a1[jt][r];
             }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int w = 0; w < 3; ++w)
-#pragma unroll
-                for (int f = 0; f < kTF; ++f)
-                    if (f < F) { sPre[w * F + f] = pre[w][f]; sA[w * F + f] = fmaxf(pre[w][f], 0.f); }
-        }
         __syncthreads();
-        if (lane < D) {      // Dense(D, relu)
-            float z = sB1[lane];
-            for (int j = 0; j < A; ++j) z = fmaf(sA[j], sW1[j * D + lane], z);
-            sZ1[lane] = z;
-            sH[lane] = fmaxf(z, 0.f);
-        }
-        __syncthreads();
-        if (lane < C) {      // Dense(C)
-            float z = sB2[lane];
-            for (int d = 0; d < D; ++d) z = fmaf(sH[d], sW2[d * C + lane], z);
-            sLg[lane] = z;
-        }
-        __syncthreads();
-        float lg[kTC], yv[kTC], glg[kTC];
+        f32x4 z1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < kTC; ++c) { lg[c] = c < C ? sLg[c] : 0.f; yv[c] = c < C ? y[idx * C + c] : 0.f; }
-        loss += (double)softmax_xent<kTC>(lg, yv, C, glg);
+        for (int i = 0; i < 8; ++i) z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kT4Yld + 4 * i + g], W1b[i], z1, 0, 0, 0);
+        f32x4 h;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z1[r] += b1v; h[r] = fmaxf(z1[r], 0.f); ys[(4 * g + r) * kT4Yld + fr] = h[r]; }      // Dense(D, relu)
+        __syncthreads();
+        f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kT4Yld + 4 * i + g], W2b[i], lg, 0, 0, 0);
+        // ---- softmax over the classes (the 16 lanes of a DPP row), Keras' cross-entropy on the probabilities, d loss / d logits
+        f32x4 glg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            auto sum16 = [](float v) { return row_allreduce(v, [](float a, float b) { return a + b; }); };
+            const float zz = cls ? lg[r] + b2v : -INFINITY;
+            const float mx = row_allreduce(zz, [](float a, float b) { return fmaxf(a, b); });
+            const float e = cls ? expf(zz - mx) : 0.f;
+            const float pv = e / sum16(e);
+            const float s = sum16(pv);
+            const float q = pv / s;
+            const float qc = fminf(fmaxf(q, kKerasEps), 1.f - kKerasEps);
+            const bool in = cls && q >= kKerasEps && q <= 1.f - kKerasEps;
+            const float li = sum16((cls && yv[r] != 0.f) ? -yv[r] * logf(qc) : 0.f);
+            const float gq = in ? -yv[r] / qc : 0.f;
+            const float gp = (gq - sum16(gq * q)) / s;
+            glg[r] = pv * (gp - sum16(gp * pv));
+            if (fr == 0) loss += (double)li;
+        }
         if (GRAD) {
-            if (lane < C) {
+            // ---- sums over the tile's frames: C/D-layout registers ARE the operands (k-step i = frames 4 (lane>>4) + i)
 #pragma unroll
-                for (int c = 0; c < kTC; ++c) if (c == lane) { sGlg[c] = glg[c]; gB2 += glg[c]; }
-            }
+            for (int i = 0; i < 4; ++i) dW2a = __builtin_amdgcn_mfma_f32_16x16x4f32(h[i], glg[i], dW2a, 0, 0, 0);      // rows d, columns c
+            gb2 += (glg[0] + glg[1]) + (glg[2] + glg[3]);
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {      // dW2[d][c] = h[d] * glg[c], entry e = lane + 64u
-                const int e = lane + 64 * u;
-                if (e < D * C) gW2[u] = fmaf(sH[e / C], sGlg[e % C], gW2[u]);
-            }
-            if (lane < D) {
-                float gh = 0.f;
-                for (int c = 0; c < C; ++c) gh = fmaf(sW2[lane * C + c], sGlg[c], gh);
-                const float gz = sZ1[lane] > 0.f ? gh : 0.f;
-                sGz1[lane] = gz;
-                gB1 += gz;
-            }
+            for (int r = 0; r < 4; ++r) ys[(4 * g + r) * kT4Yld + fr] = glg[r];
+            __syncthreads();
+            f32x4 dz1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dz1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kT4Yld + 4 * i + g], W2t[i], dz1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[r] = z1[r] > 0.f ? dz1[r] : 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dW1a[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[jt][i], dz1[i], dW1a[jt], 0, 0, 0);      // rows j, columns d
+            gb1 += (dz1[0] + dz1[1]) + (dz1[2] + dz1[3]);
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {      // dW1[j][d] = a[j] * gz1[d]
-                const int e = lane + 64 * u;
-                if (e < A * D) gW1[u] = fmaf(sA[e / D], sGz1[e % D], gW1[u]);
-            }
-            if (lane < A) {
-                float ga = 0.f;
-                for (int d = 0; d < D; ++d) ga = fmaf(sW1[lane * D + d], sGz1[d], ga);
-                sGa[lane] = sPre[lane] > 0.f ? ga : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) ys[(4 * g + r) * kT4Yld + fr] = dz1[r];
             __syncthreads();
+            f32x4 dpre[2];
 #pragma unroll
-            for (int f = 0; f < kTF; ++f)
-                if (f < F) {
-                    const float g0 = sGa[f], g1 = sGa[F + f], g2 = sGa[2 * F + f];
+            for (int jt = 0; jt < 2; ++jt) {
+                f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        gK[u][1][f] = fmaf(g0, xi[u], fmaf(g1, xq[u], gK[u][1][f]));
-                        gK[u][0][f] = fmaf(g1, xi[u], fmaf(g2, xq[u], gK[u][0][f]));
-                    }
-                    if (lane == f) gCb += g0 + g1 + g2;
+                for (int i = 0; i < 4; ++i) da = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kT4Yld + 4 * i + g], W1t[jt][i], da, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dpre[jt][r] = pre[jt][r] > 0.f ? da[r] : 0.f;
+                gcb[jt] += (dpre[jt][0] + dpre[jt][1]) + (dpre[jt][2] + dpre[jt][3]);
+            }
+#pragma unroll
+            for (int T = 0; T < 16; ++T)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xa = xs[(4 * g + i) * kT4Xld + 16 * T + fr];      // A[row = input 16T + fr][k = frame 4g + i]
+                    dM[T][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, dpre[0][i], dM[T][0], 0, 0, 0);
+                    dM[T][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, dpre[1][i], dM[T][1], 0, 0, 0);
                 }
         }
-        __syncthreads();      // the s* vectors are rewritten by the next frame
+        __syncthreads();      // xs / ys are rewritten by the next tile
     }
-    if (lane == 0) loss_partials[g] = loss;
+    // ---- the wave's loss (lanes fr == 0 hold the rows of their g) and its partial gradient vector (internal layout)
+    if (fr == 0) sloss[g] = loss;
+    __syncthreads();
+    if (lane == 0) loss_partials[blockIdx.x] = (sloss[0] + sloss[1]) + (sloss[2] + sloss[3]);
     if (!GRAD) return;
-    float* out = partials + (size_t)g * P;
+    float* out = partials + (size_t)blockIdx.x * kT4Pint;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int T = 0; T < 16; ++T)
 #pragma unroll
-        for (int kw = 0; kw < 2; ++kw)
+        for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int f = 0; f < kTF; ++f)
-                if (f < F) out[(kw * 128 + lane + 64 * u) * F + f] = gK[u][kw][f];
-    if (lane < F) out[offCb + lane] = gCb;
+            for (int r = 0; r < 4; ++r) out[kT4Mc + (16 * T + 4 * g + r) * 32 + 16 * jt + fr] = dM[GRAD ? T : 0][jt][r];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int e = lane + 64 * u; if (e < A * D) out[offW1 + e] = gW1[u]; }
-    if (lane < D) out[offB1 + lane] = gB1;
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u; if (e < D * C) out[offW2 + e] = gW2[u]; }
-    if (lane < C) out[offB2 + lane] = gB2;
-    if (lane == 0 && bump_iter && g == 0) st->iterations += 1;
+        for (int r = 0; r < 4; ++r) out[kT4W1 + (16 * jt + 4 * g + r) * 16 + fr] = dW1a[jt][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[kT4W2 + (4 * g + r) * 16 + fr] = dW2a[r];
+    // column sums: over the four lane groups (xor 16, 32: the same bits in every lane)
+    auto over_g = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    const float c0 = over_g(gcb[0]), c1 = over_g(gcb[1]), s1 = over_g(gb1), s2 = over_g(gb2);
+    if (g == 0) { out[kT4Cb + fr] = c0; out[kT4Cb + 16 + fr] = c1; out[kT4B1 + fr] = s1; out[kT4B2 + fr] = s2; }
+    if (lane == 0 && bump_iter && blockIdx.x == 0) st->iterations += 1;
 }
 
 // ---- fixed-order reduction of the partials + TensorFlow 2.4's Adam.  Block = 64 parameters x 16 slices of the G partials: a
@@ -379,7 +441,8 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
 constexpr int kRedSlices = 16;
 
 __global__ __launch_bounds__(1024) void train_adam_kernel(const float* __restrict__ partials, const double* __restrict__ loss_partials, int G,
-                                                         int P, int count, int mode, float lr, float beta1, float beta2, float eps,
+                                                         int P, int Pint, const int* __restrict__ map, int count, int mode, float lr,
+                                                         float beta1, float beta2, float eps,
                                                          float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                                                          float* __restrict__ grad, TrainState* __restrict__ st) {
     __shared__ float part[kRedSlices][64];
@@ -390,16 +453,22 @@ __global__ __launch_bounds__(1024) void train_adam_kernel(const float* __restric
         float acc = 0.f;
         if (i < P) {
             const int per = (G + kRedSlices - 1) / kRedSlices, lo = slice * per, hi = min(G, lo + per);
-            const float* src = partials + (size_t)lo * P + i;
-            int w = lo;
-            for (; w + 16 <= hi; w += 16, src += (size_t)16 * P) {
-                float t[16];
+            // parameter i = the sum of up to three entries of a partial vector (one for the deployed nets; cnn.py's conv weights
+            // are two entries of dMc, its conv bias three column sums): entry by entry, partials lo .. hi in order
+            for (int e = 0; e < 3; ++e) {
+                const int me = map[3 * i + e];
+                if (me < 0) break;
+                const float* src = partials + (size_t)lo * Pint + me;
+                int w = lo;
+                for (; w + 16 <= hi; w += 16, src += (size_t)16 * Pint) {
+                    float t[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] = src[(size_t)u * P];
+                    for (int u = 0; u < 16; ++u) t[u] = src[(size_t)u * Pint];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc += t[u];
+                    for (int u = 0; u < 16; ++u) acc += t[u];
+                }
+                for (; w < hi; ++w, src += Pint) acc += *src;
             }
-            for (; w < hi; ++w, src += P) acc += *src;
         }
         part[slice][col] = acc;
         __syncthreads();
@@ -461,7 +530,32 @@ int trainer_layout(mdc_trainer* t) {
         t->off_b[l] = off; off += t->nb[l];
     }
     t->P = off;
+    t->Pint = tp.kind == MDC_KIND_CNNPY ? (size_t)kT4Pint : off;
     return MDC_OK;
+}
+
+// [P][3] index map from Keras' parameter order into a partial vector (see train_adam_kernel)
+std::vector<int> trainer_map(const mdc_trainer* t) {
+    std::vector<int> m(t->P * 3, -1);
+    if (t->topo.kind != MDC_KIND_CNNPY) {
+        for (size_t i = 0; i < t->P; ++i) m[3 * i] = (int)i;
+        return m;
+    }
+    const int F = t->topo.filters, D = t->topo.hidden, C = t->topo.classes;
+    auto set = [&](size_t i, int a, int b = -1, int c = -1) { m[3 * i] = a; m[3 * i + 1] = b; m[3 * i + 2] = c; };
+    for (int c = 0; c < 128; ++c)
+        for (int f = 0; f < F; ++f) {
+            set(t->off_k[0] + (size_t)(0 * 128 + c) * F + f, kT4Mc + c * 32 + F + f, kT4Mc + (128 + c) * 32 + 2 * F + f);      // tap 0: (I, w = 1), (Q, w = 2)
+            set(t->off_k[0] + (size_t)(1 * 128 + c) * F + f, kT4Mc + c * 32 + f, kT4Mc + (128 + c) * 32 + F + f);              // tap 1: (I, w = 0), (Q, w = 1)
+        }
+    for (int f = 0; f < F; ++f) set(t->off_b[0] + f, kT4Cb + f, kT4Cb + F + f, kT4Cb + 2 * F + f);
+    for (int j = 0; j < 3 * F; ++j)
+        for (int d = 0; d < D; ++d) set(t->off_k[1] + (size_t)j * D + d, kT4W1 + j * 16 + d);
+    for (int d = 0; d < D; ++d) set(t->off_b[1] + d, kT4B1 + d);
+    for (int d = 0; d < D; ++d)
+        for (int c = 0; c < C; ++c) set(t->off_k[2] + (size_t)d * C + c, kT4W2 + d * 16 + c);
+    for (int c = 0; c < C; ++c) set(t->off_b[2] + c, kT4B2 + c);
+    return m;
 }
 
 int waves_for(const mdc_trainer* t, int64_t count) {
@@ -469,7 +563,8 @@ int waves_for(const mdc_trainer* t, int64_t count) {
     // for the nets whose partial vector is small (T1: 2,334 floats, T4: 2,935 -- 512 waves for the reference's 1,024-frame
     // batch), four for the 10-filter net (7,773 floats per partial: the reduction's traffic would double); never more than
     // kMaxWaves (evaluation of a large set then walks count / 1,024 frames per wave with every CU busy).
-    const int per_wave = (t->topo.kind == MDC_KIND_DEPLOYED && t->topo.filters == 10) ? 4 : 2;
+    // cnn.py's net: one wave per 16-frame MFMA tile.
+    const int per_wave = t->topo.kind == MDC_KIND_CNNPY ? 16 : (t->topo.filters == 10 ? 4 : 2);
     int64_t g = (count + per_wave - 1) / per_wave;
     if (g < 1) g = 1;
     if (g > kMaxWaves) g = kMaxWaves;
@@ -498,7 +593,7 @@ int launch_batch(mdc_trainer* t, const float* x, const float* y, const int32_t* 
     MDC_HIP(hipGetLastError());
     const int P = (int)t->P;
     const int blocks = mode == 0 ? 1 : (P + 63) / 64;
-    hipLaunchKernelGGL(train_adam_kernel, dim3(blocks), dim3(1024), 0, s, t->d_partials, t->d_loss_partials, G, P, cnt, mode, t->lr, t->beta1, t->beta2,
+    hipLaunchKernelGGL(train_adam_kernel, dim3(blocks), dim3(1024), 0, s, t->d_partials, t->d_loss_partials, G, P, (int)t->Pint, t->d_map, cnt, mode, t->lr, t->beta1, t->beta2,
                        t->eps, t->d_params, t->d_m, t->d_v, t->d_grad, st);
     MDC_HIP(hipGetLastError());
     return MDC_OK;
@@ -548,7 +643,8 @@ int mdc_trainer_create(const mdc_topology* topo, int device, mdc_trainer** out) 
         const size_t pb = t->P * sizeof(float);
         auto fail = [&](int code) { mdc_trainer_destroy(t); return code; };
         if (hipMalloc(&t->d_params, pb) != hipSuccess || hipMalloc(&t->d_m, pb) != hipSuccess || hipMalloc(&t->d_v, pb) != hipSuccess ||
-            hipMalloc(&t->d_grad, pb) != hipSuccess || hipMalloc(&t->d_partials, pb * kMaxWaves) != hipSuccess ||
+            hipMalloc(&t->d_grad, pb) != hipSuccess || hipMalloc(&t->d_partials, t->Pint * sizeof(float) * kMaxWaves) != hipSuccess ||
+            hipMalloc(&t->d_map, t->P * 3 * sizeof(int)) != hipSuccess ||
             hipMalloc(&t->d_loss_partials, sizeof(double) * kMaxWaves) != hipSuccess || hipMalloc(&t->d_state, sizeof(TrainState)) != hipSuccess) {
             set_error("mdc_trainer_create: out of device memory");
             return fail(MDC_ENOMEM);
@@ -556,6 +652,11 @@ int mdc_trainer_create(const mdc_topology* topo, int device, mdc_trainer** out) 
         if (hipMemset(t->d_params, 0, pb) != hipSuccess || hipMemset(t->d_m, 0, pb) != hipSuccess || hipMemset(t->d_v, 0, pb) != hipSuccess ||
             hipMemset(t->d_grad, 0, pb) != hipSuccess || hipMemset(t->d_state, 0, sizeof(TrainState)) != hipSuccess) {
             set_error("mdc_trainer_create: hipMemset failed");
+            return fail(MDC_EIO);
+        }
+        const std::vector<int> map = trainer_map(t);
+        if (hipMemcpy(t->d_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("mdc_trainer_create: hipMemcpy failed");
             return fail(MDC_EIO);
         }
         *out = t;
@@ -707,7 +808,7 @@ void mdc_trainer_destroy(mdc_trainer* t) {
     if (!t) return;
     {
         DeviceScope dev(t->device);
-        for (void* p : {(void*)t->d_params, (void*)t->d_m, (void*)t->d_v, (void*)t->d_grad, (void*)t->d_partials, (void*)t->d_loss_partials, t->d_state})
+        for (void* p : {(void*)t->d_params, (void*)t->d_m, (void*)t->d_v, (void*)t->d_grad, (void*)t->d_partials, (void*)t->d_loss_partials, t->d_state, (void*)t->d_map})
             if (p) (void)hipFree(p);
     }
     delete t;

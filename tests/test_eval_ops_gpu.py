@@ -339,3 +339,25 @@ def test_crossentropy_entry_point_accumulates_and_validates():
     assert L.mdc_crossentropy(p.data_ptr(), t.data_ptr(), 2, 3, None, None, None) == -22
     assert L.mdc_crossentropy(p.data_ptr(), t.data_ptr(), 2, 99, acc.data_ptr(), None, None) == -22 and b"classes" in L.mdc_last_error()
     assert L.mdc_crossentropy(None, None, 0, 3, acc.data_ptr(), None, None) == 0
+
+
+def test_crossentropy_propagates_nan_like_keras():
+    """a NaN probability row (NaN / Inf samples in, or a row summing to 0) must make the score NaN, as Keras'
+    clip_by_value leaves it and as the numpy oracle's np.clip does -- fmaxf alone would turn it into 1e-7 and the mean loss
+    into a finite number."""
+    from modulationdetectioncnn_amd import _cabi
+    from oracle import oracle_np as O
+    L = _cabi.lib()
+    p = torch.tensor([[0.2, 0.5, 0.3], [float("nan"), 0.5, 0.5], [0.0, 0.0, 0.0]], dtype=torch.float32, device="cuda")
+    for rows, nan in (((0,), False), ((0, 1), True), ((0, 2), True)):
+        pp = p[list(rows)].contiguous()
+        t = torch.zeros(len(rows), dtype=torch.int32, device="cuda")
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+        _cabi.check(L.mdc_crossentropy(pp.data_ptr(), t.data_ptr(), len(rows), 3, acc.data_ptr(), None, None))
+        got = float(acc.item()) / len(rows)
+        want = O.categorical_crossentropy(pp.cpu().numpy(), t.cpu().numpy())
+        assert np.isnan(got) == nan == bool(np.isnan(want)), (rows, got, want)
+        if not nan:
+            assert got == pytest.approx(want, rel=1e-6)
+    # (Through VTCNN2.evaluate the score of a frame holding a NaN SAMPLE is a property of the forward kernels, not of this entry
+    # point: the deployed f32 kernels' clamp-bit ReLU turns a NaN activation into 0 -- include/mdc.h, "documented range".)

@@ -121,6 +121,29 @@ def test_round_trip_bit_identical(tmp_path, kind):
             assert f.get("optimizer_weights").attrs["weight_names"][0] == "Adam/iter:0"
 
 
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="no h5dump in this image")
+@pytest.mark.parametrize("kind", ["deployed10", "cnnpy", "vtcnn2"])
+def test_libhdf5_walks_every_topologys_file(tmp_path, kind):
+    """h5dump (the real libhdf5) walks the whole file of every topology without a complaint and finds every dataset with its
+    shape -- the 13-layer VT-CNN2 spreads /model_weights over two symbol-table nodes under one B-tree node."""
+    topo = {"deployed10": Topology.deployed(10), "cnnpy": Topology.cnnpy(10, 10, 5), "vtcnn2": Topology.vtcnn2(11)}[kind]
+    w = synthetic_weights(topo, seed=2)
+    opt = {"iterations": 7, "m": w, "v": w}
+    path = str(tmp_path / "f.h5")
+    write_keras_h5(path, topo, w, optimizer=opt)
+    r = subprocess.run([H5DUMP, "-H", path], capture_output=True, text=True)
+    assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+    names = [n for _, n in topo.keras_layer_names()]
+    for role, lname in topo.keras_layer_names():
+        assert f'GROUP "{lname}"' in r.stdout
+    for (ks, bs), lname in zip(topo.layer_shapes, [n for role, n in topo.keras_layer_names() if role in ("conv", "dense")]):
+        dims = ", ".join(str(d) for d in ks)
+        assert f"DATASPACE  SIMPLE {{ ( {dims} ) / ( {dims} ) }}" in r.stdout, (lname, dims)
+    assert r.stdout.count('DATASET "kernel:0"') == len(topo.layer_shapes)
+    assert r.stdout.count('DATASET "m:0"') == 2 * len(topo.layer_shapes) and 'DATASET "iter:0"' in r.stdout
+    assert len(names) == len(set(names))
+
+
 @pytest.mark.skipif(not os.path.exists(LIBHDF5), reason="no libhdf5 in this image")
 def test_libhdf5_reads_the_tensors_through_its_c_api(tmp_path):
     """H5Fopen + H5Dopen2 + H5Dread -- the calls behind h5py's `f['model_weights/...'][()]` in Keras' load_weights."""
