@@ -57,3 +57,37 @@ def test_collectives_of_the_evaluation_path_under_rccl_world1():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "NCCL-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+CHILD_BENCH = r'''
+import os, sys, socket
+sys.path.insert(0, %r)
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)          # a rank somebody else's launcher started with a bare environment
+import bench
+bench.rank_environment(os.environ)
+assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+import torch
+bench.select_device(0)
+dist = bench.init_distributed(0)                             # "nccl" with device_id = this rank's GPU
+assert str(dist.get_backend()).lower() == "nccl"
+from modulationdetectioncnn_amd import sharding
+import time
+el = sharding.timed_region(lambda: time.sleep(0.002), steps=2, warmup=1, sync=torch.cuda.synchronize, device=torch.device("cuda", 0))
+assert el >= 0.004
+assert bench.agree_ok(dist, True, "leg")
+dist.barrier()
+dist.destroy_process_group()
+print("BENCH-RCCL-OK")
+''' % ROOT
+
+
+@pytest.mark.gpu
+def test_bench_rank_initialisation_under_rccl_world1():
+    """bench.py's own rank set-up on the real backend (VERDICT r4 item 6): the environment every rank gets, RCCL bound to the rank's
+    GPU with device_id, the barriers and the MAX-reduce of the timing contract and the leg agreement, at the largest world a one-GPU
+    box can form."""
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    r = subprocess.run([sys.executable, "-c", CHILD_BENCH], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "BENCH-RCCL-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
