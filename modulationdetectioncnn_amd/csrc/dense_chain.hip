@@ -38,6 +38,23 @@ struct ChainParams {
     int n1, n2;            // real widths of layers 1, 2 (for the taps)
 };
 
+// 16 B per lane from global memory straight into LDS (destination = wave-uniform base + 16 lane), issued from asm: hipcc puts
+// an s_waitcnt vmcnt(0) in front of every LDS read that follows a BUILTIN LDS-DMA (vtcnn2_bf16_common.h, glds16_async), which
+// would drain the prefetch below at once.  The kernel orders both ways itself: vmcnt(0) at the end of a tile before the next one
+// reads the buffer, lgkmcnt(0) before a buffer is refilled.
+__device__ __forceinline__ void chain_glds16(const void* gsrc, void* lds_wave_base) {
+    const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+    asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(gsrc), "{m0}"(l) : "memory");
+}
+
+// Round 5.  Before: a wave loaded its 16 rows into registers, waited, wrote them to LDS, then ran layer 1 as ONE or two dependent
+// MFMA chains (the K order is the result) -- 268 registers, so one wave per SIMD, nothing to fill the chain's latency or the
+// load's: cnn.py's model streamed at 0.34 of the HBM peak (93 cycles per 32-cycle MFMA).  Now the rows travel by LDS-DMA (no
+// staging registers: 219, TWO waves per SIMD whose chains interleave), and a wave refills its buffer with the NEXT tile as soon as
+// layer 1 has read it, under layers 2 - 3, the softmax and the stores.  A second LDS buffer per wave instead (the whole tile ahead)
+// costs the second wave per SIMD and bought 12 %; this form 29 %: 3.4e9 frames/s = 0.44 of the HBM peak, same bits
+// (profiles/r05_dense_chain_ab.log).  What is left is the chain itself: two waves x two dependent MFMA chains per SIMD.
+// Rows past the end of the batch: the last row again (a valid address); they are computed and never stored.
 template <int T1, int NL>
 __global__ __launch_bounds__(256) void dense_chain_kernel(ChainParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -45,6 +62,14 @@ __global__ __launch_bounds__(256) void dense_chain_kernel(ChainParams p) {
     const int fr = lane & 15, g = lane >> 4;
     float* xs = smem + wv * (16 * kXld + 16 * kYld);
     float* ys = xs + 16 * kXld;
+    auto stage = [&](long tile) {
+        const long r0 = tile << 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = r0 + r < p.n ? r0 + r : p.n - 1;
+            chain_glds16(p.x + row * kK0 + 4 * lane, xs + r * kXld);
+        }
+    };
 
     // ---- weights into registers (B operands: lane (col = fr, k-group g) holds W[4i + g][col]) ----
     float w1[T1][64];
@@ -66,18 +91,11 @@ __global__ __launch_bounds__(256) void dense_chain_kernel(ChainParams p) {
 
     const long ntiles = (p.n + 15) >> 4;
     const long nwaves = (long)gridDim.x * 4;
-    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += nwaves) {
+    long tile = (long)blockIdx.x * 4 + wv;
+    if (tile < ntiles) stage(tile);
+    for (; tile < ntiles; tile += nwaves) {
         const long row0 = tile << 4;
-        // ---- stage 16 rows (1 KiB each): one coalesced float4 per lane per row ----
-        float4 v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < p.n) v[r] = reinterpret_cast<const float4*>(p.x + (row0 + r) * kK0)[lane];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) *reinterpret_cast<float4*>(xs + r * kXld + 4 * lane) = v[r];
-        // (single wave: LDS ordering within the wave needs no barrier, only the waits hipcc inserts)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed (issued in the prologue / under the previous tile's tail)
 
         // ---- layer 1: K = 256 ----
         f32x4 acc[T1];
@@ -89,6 +107,9 @@ __global__ __launch_bounds__(256) void dense_chain_kernel(ChainParams p) {
 #pragma unroll
             for (int t = 0; t < T1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w1[t][i], acc[t], 0, 0, 0);
         }
+        // every read of xs has fed an MFMA above; say so, then refill the buffer with the wave's next tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tile + nwaves < ntiles) stage(tile + nwaves);
         f32x4 z;      // final-layer pre-softmax values: lane (class = fr), rows 4g + r
         if (NL == 1) {
 #pragma unroll
@@ -147,7 +168,7 @@ int chain_launch(int t1, int nl, const float* x, long n, const float* wpack, int
     ChainParams p{x, n, wpack, nl, n_out, relu1, relu2, probs, labels, tap_logits, tap_h1, tap_h2, n1, n2};
     const long ntiles = (n + 15) / 16;
     long grid = (ntiles + 3) / 4;
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;      // persistent: two work-groups per CU (LDS and registers allow exactly that), each wave walking its tiles
     const size_t lds = (size_t)4 * (16 * kXld + 16 * kYld) * sizeof(float);    // 75,776 B
     const void* fn = nullptr;
     if (t1 == 1 && nl == 1) fn = reinterpret_cast<const void*>(dense_chain_kernel<1, 1>);
