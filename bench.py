@@ -76,7 +76,8 @@ WORKLOADS = {
 }
 DEFAULT = "vtcnn2-c11-bf16-n2^20"
 EXTRAS = ["vtcnn2-c3-f32-n65536", "vtcnn2-c11-fp8-n2^20", "deployed3-f32-n2^20", "deployed10-f32-n2^20",
-          "deployed3-bf16-n2^20", "deployed10-bf16-n2^20", "deployed3-f16-n2^20", "deployed10-f16-n2^20", "deployed3-fp8-n2^20"]
+          "deployed3-bf16-n2^20", "deployed10-bf16-n2^20", "deployed3-f16-n2^20", "deployed10-f16-n2^20", "deployed3-fp8-n2^20",
+          "cnnpy-f32-n2^20"]
 
 
 def make_model(name, device):

@@ -68,3 +68,59 @@ def test_c_client_reproduces_the_oracle(tmp_path, n, lanes):
         srt = np.sort(ref["dense"], axis=1)
         decided = (srt[:, -1] - srt[:, -2]) > 1e-5 * np.maximum(np.abs(ref["dense"]).max(axis=1), 1e-30)
         assert (labels[decided] == ref["labels"][decided]).all()
+
+
+TRAIN_SRC = os.path.join(ROOT, "examples", "c_train_client.c")
+
+
+def _build_train_client(tmp_path):
+    import modulationdetectioncnn_amd.build as b
+    lib = b.build()
+    exe = tmp_path / "c_train_client"
+    subprocess.run(CFLAGS + [TRAIN_SRC, "-L", os.path.dirname(lib), "-lmdc", "-L", os.path.join(ROCM, "lib"), "-lamdhip64",
+                             f"-Wl,-rpath,{os.path.dirname(lib)}", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_c_train_client_compiles_as_plain_c99(tmp_path):
+    exe = _build_train_client(tmp_path)
+    needed = subprocess.run(["readelf", "-d", str(exe)], check=True, capture_output=True, text=True).stdout
+    libs = [ln.split("[")[1].rstrip("]") for ln in needed.splitlines() if "NEEDED" in ln]
+    assert any(x.startswith("libmdc") for x in libs) and not any("stdc++" in x or "torch" in x or "python" in x for x in libs), libs
+
+
+@pytest.mark.gpu
+def test_c_train_client_reproduces_the_oracles_fit(tmp_path):
+    """cnn.py:113, 122-147 from plain C through mdc_trainer_* / mdc_train_batch: the per-epoch loss and val_loss and the
+    best-epoch weights equal the numpy oracle's fit on the same permutations (parity unpinned: no dataset, no recorded run)."""
+    from modulationdetectioncnn_amd import Topology, synthetic_weights
+    from oracle import oracle_train as T
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from signals import modulated_frames
+    exe = _build_train_client(tmp_path)
+    n, nv, epochs, batch = 1500, 500, 6, 512
+    x, lab, _ = modulated_frames(n + nv, seed=5)
+    x = (x * np.array([0.4, 1.0, 2.2], np.float32)[lab][:, None, None]).astype(np.float32)
+    y = T.onehot(lab, 3, np.float32)
+    topo = Topology.deployed(3)
+    w = synthetic_weights(topo, seed=9)
+    np.concatenate([np.asarray(a, np.float32).ravel() for pair in w for a in pair]).tofile(tmp_path / "w.bin")
+    x.tofile(tmp_path / "x.bin")
+    y.tofile(tmp_path / "y.bin")
+    r = subprocess.run([str(exe), str(tmp_path / "w.bin"), str(tmp_path / "x.bin"), str(tmp_path / "y.bin"), str(n), str(nv), str(epochs),
+                        str(batch), str(tmp_path / "out.bin"), "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+    raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint8)
+    hist = raw[: epochs * 16].view(np.float64).reshape(epochs, 2)
+    got_w = raw[epochs * 16:].view(np.float32)
+    perms = [((7919 * np.arange(n, dtype=np.int64) + 13 * ep) % n) for ep in range(epochs)]
+    assert all(len(set(p.tolist())) == n for p in perms)
+    ref = T.fit("deployed", w, x[:n].astype(np.float64), y[:n].astype(np.float64), batch, epochs, (x[n:].astype(np.float64), y[n:].astype(np.float64)),
+                patience=5, permutations=lambda ep: perms[ep], dtype=np.float64)
+    k = len(ref["loss"])
+    assert (hist[k:] == -1).all()
+    np.testing.assert_allclose(hist[:k, 0], ref["loss"], rtol=2e-5)
+    np.testing.assert_allclose(hist[:k, 1], ref["val_loss"], rtol=2e-5)
+    want = np.concatenate([np.asarray(a, np.float32).ravel() for pair in ref["best_weights"] for a in pair])
+    assert np.abs(got_w - want).max() <= 1e-4
+    assert f"Adam step {3 * k}" in r.stdout                      # 1,500 frames in batches of 512: 512 + 512 + 476
