@@ -274,7 +274,8 @@ MDC_API int mdc_profile_reset(mdc_model* m);
  * Everything below runs on the trainer's device; x_dev (frames (., 2, 128) f32, 16-byte aligned) and y_dev (target rows
  * (., classes) f32: the one-hot rows of cnn.py:74-82, or any distribution) are the caller's buffers holding the WHOLE set;
  * a mini-batch is the frames order_dev[first .. first + count) of it (order_dev: int32 indices on the device, the
- * epoch's shuffle -- frames are never moved; NULL = the identity).  mdc_train_batch and mdc_trainer_evaluate only enqueue
+ * epoch's shuffle -- frames are never moved; NULL = the identity; every index must address a frame of the buffers: the
+ * library cannot check device memory).  mdc_train_batch and mdc_trainer_evaluate only enqueue
  * on hip_stream (two launches, no synchronisation, no allocation: capturable in a hipGraph; Adam's step count lives on the
  * device).  A step is reproducible bit for bit (fixed-order reductions, no float atomics).  One stream at a time per trainer. */
 typedef struct mdc_trainer mdc_trainer;   /* opaque: f32 master weights in the Keras layouts, Adam state, scratch */

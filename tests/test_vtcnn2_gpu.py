@@ -84,9 +84,11 @@ def test_taps(dtype):
     tol = TOL[dtype]
     flat = m.predict(x, tap="flat")
     assert flat.shape == (40, 10560)
-    # fp8 mode (round 4): the features themselves are E4M3 values (x a power of two) -- a value v in [2^e, 2^(e+1)) sits
-    # within 2^(e-4) <= v/16 of its byte, on top of the conv's own error
-    flat_tol = tol + (1.0 / 16 if dtype == "fp8" else 0.0)
+    # fp8 mode (round 4): the features themselves are E4M3 values (x a power of two), rounded to nearest on a grid whose
+    # spacing is 1/8 of the binade's base: half a spacing = at most 1/16 of the value at the bottom of a binade, 1/32 at the
+    # top -- on top of the conv's own error.  Bar: tol + 1/32 of the largest feature (round 4 allowed tol + 1/16 after a red
+    # run; measured 6.06 % with E4M3 features, 3.7 % with bf16 features: profiles/r05_measured_bars.json)
+    flat_tol = tol + (1.0 / 32 if dtype == "fp8" else 0.0)
     assert np.abs(flat - ref["flat"]).max() <= flat_tol * np.abs(ref["flat"]).max()
     conv = m.predict(x, tap="conv")
     assert conv.shape == (40, 80, 132)
