@@ -195,13 +195,19 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
 // The per-element accumulation order (K-tiles ascending, k-steps of 4 ascending, one MFMA chain per output tile) is that
 // of the old kernel and of vt_dense1_f32_small_kernel: bit-identical hidden layer (tests/test_fullsize_gpu.py).
 // ------------------------------------------------------------------------------------
+// ROWS = 128 (the batch kernel) or 64: the same kernel on half-height tiles for batches that would leave CUs idle at 128 rows
+// (n <= 16,384: at most 256 tiles of 64 rows; the 128 x 128 tiles of rounds 1-4 had twice the work-groups per frame, and at
+// n = 4,096 the 128-row form alone was slower than they were).  Same per-element order: bit-identical at every size.
 constexpr int kDM = 128, kDK = 32;
 constexpr int kDAld = 34, kDBld = 272;
-constexpr int kDABuf = kDM * kDAld, kDBBuf = kDK * kDBld;                    // floats per buffer
-constexpr size_t kDense1F32Lds = (size_t)kDM * kChainXld * sizeof(float);   // the epilogue's [128][260] image (133,120 B) > 2 x (A + B) = 106,496 B
-static_assert(kDense1F32Lds >= 2 * (kDABuf + kDBBuf) * sizeof(float), "the staging buffers must fit under the epilogue image");
+constexpr int kDBBuf = kDK * kDBld;                                          // floats per B buffer
+template <int ROWS> constexpr size_t dense1_f32_lds() {                      // the epilogue's [ROWS][260] image or the staging buffers, whichever is larger
+    const size_t img = (size_t)ROWS * kChainXld * sizeof(float), stg = 2 * ((size_t)ROWS * kDAld + kDBBuf) * sizeof(float);
+    return img > stg ? img : stg;
+}
+constexpr size_t kDense1F32Lds = dense1_f32_lds<128>();                      // 133,120 B
 
-template <bool HEAD>
+template <bool HEAD, int ROWS>
 __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restrict__ feat, long n,
                                                             const float* __restrict__ w1p,   // [10560][256]
                                                             const float* __restrict__ c1,    // [256]
@@ -209,23 +215,25 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
                                                             const float* __restrict__ w2pack, int n_out,
                                                             float* __restrict__ probs, int* __restrict__ labels) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    float* As = dsm;                    // [2][128][34]
+    constexpr int kDABuf = ROWS * kDAld, RI = ROWS / 32;      // floats per A buffer; 16-row fragments per wave (its ROWS/2 rows)
+    float* As = dsm;                    // [2][ROWS][34]
     float* Bs = dsm + 2 * kDABuf;       // [2][32][272]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 2, wc = wv & 3;
     const int fr = lane & 15, fq = lane >> 4;
-    const long row0 = (long)blockIdx.x * kDM;
-    f32x4 acc[4][4];
+    const long row0 = (long)blockIdx.x * ROWS;
+    f32x4 acc[RI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging: A tile 128 rows x 32 k = 1024 float4, two per thread (8 consecutive threads = one row's 128 B);
-    //          B tile 32 k x 256 cols = 2048 float4, four per thread (one wave = one k row's 1 KiB)
-    const int ar0 = tid >> 3, ak4 = (tid & 7) * 4;           // A rows ar0 and ar0 + 64
+    // staging: A tile ROWS rows x 32 k = ROWS * 8 float4, one (64 rows) or two (128) per thread (8 consecutive threads = one
+    //          row's 128 B); B tile 32 k x 256 cols = 2048 float4, four per thread (one wave = one k row's 1 KiB)
+    constexpr bool kTwoA = ROWS == 128;
+    const int ar0 = tid >> 3, ak4 = (tid & 7) * 4;           // A rows ar0 and (128-row tiles) ar0 + 64
     const int bk0 = tid >> 6, bc4 = (tid & 63) * 4;           // B rows bk0, +8, +16, +24
-    const bool aok0 = row0 + ar0 < n, aok1 = row0 + ar0 + 64 < n;      // rows past the end: zeros, computed, never stored
+    const bool aok0 = row0 + ar0 < n, aok1 = kTwoA && row0 + ar0 + 64 < n;      // rows past the end: zeros, computed, never stored
     const float* ap0 = feat + (aok0 ? row0 + ar0 : 0) * (long)kFeat + ak4;
     const float* ap1 = feat + (aok1 ? row0 + ar0 + 64 : 0) * (long)kFeat + ak4;
     // (named registers, not arrays: hipcc kept float4 arrays captured by these lambdas in scratch)
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
         // between two addresses and park the zeros in scratch
         // ... and selected in stash(), a K-tile later: selecting here would wait for the load right behind its issue)
         ga0 = *reinterpret_cast<const float4*>(ap0 + k0);
-        ga1 = *reinterpret_cast<const float4*>(ap1 + k0);
+        if (kTwoA) ga1 = *reinterpret_cast<const float4*>(ap1 + k0);
         const float* b = bp + (size_t)k0 * kHid;
         gb0 = *reinterpret_cast<const float4*>(b);
         gb1 = *reinterpret_cast<const float4*>(b + 8 * kHid);
@@ -248,8 +256,10 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
         const float4 v0 = aok0 ? ga0 : make_float4(0.f, 0.f, 0.f, 0.f), v1 = aok1 ? ga1 : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float2*>(a) = make_float2(v0.x, v0.y);
         *reinterpret_cast<float2*>(a + 2) = make_float2(v0.z, v0.w);
-        *reinterpret_cast<float2*>(a + 64 * kDAld) = make_float2(v1.x, v1.y);
-        *reinterpret_cast<float2*>(a + 64 * kDAld + 2) = make_float2(v1.z, v1.w);
+        if (kTwoA) {
+            *reinterpret_cast<float2*>(a + 64 * kDAld) = make_float2(v1.x, v1.y);
+            *reinterpret_cast<float2*>(a + 64 * kDAld + 2) = make_float2(v1.z, v1.w);
+        }
         float* d = Bs + b * kDBBuf + bk0 * kDBld + bc4;
         *reinterpret_cast<float4*>(d) = gb0;
         *reinterpret_cast<float4*>(d + 8 * kDBld) = gb1;
@@ -266,17 +276,17 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
         // the loads above are ISSUED here, one K-tile ahead of their use: left to itself hipcc sinks them behind the MFMAs and
         // waits for them at once (the whole global-load latency exposed at the end of every K-tile: 3.30 ms per 65,536 frames)
         __builtin_amdgcn_sched_barrier(0);
-        const float* Ab = As + b * kDABuf + (wr * 64 + fr) * kDAld + fq;
+        const float* Ab = As + b * kDABuf + (wr * (ROWS / 2) + fr) * kDAld + fq;
         const float* Bb = Bs + b * kDBBuf + fq * kDBld + wc * 64 + fr;
 #pragma unroll
         for (int kk = 0; kk < kDK; kk += 4) {
-            float a[4], bv[4];
+            float a[RI], bv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = Ab[i * 16 * kDAld + kk];
+            for (int i = 0; i < RI; ++i) a[i] = Ab[i * 16 * kDAld + kk];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = Bb[kk * kDBld + j * 16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
@@ -288,14 +298,14 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
     // C/D layout: col = lane&15, row = 4*(lane>>4) + reg
     if constexpr (!HEAD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = wc * 64 + j * 16 + fr;
                 const float bias = c1[col];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const long row = row0 + wr * 64 + i * 16 + fq * 4 + r;
+                    const long row = row0 + wr * (ROWS / 2) + i * 16 + fq * 4 + r;
                     if (row < n) hid[row * kHid + col] = fmaxf(acc[i][j][r] + bias, 0.f);
                 }
             }
@@ -308,23 +318,25 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
             const int col = wc * 64 + j * 16 + fr;
             const float bias = c1[col];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RI; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xs[(wr * 64 + i * 16 + fq * 4 + r) * kChainXld + col] = fmaxf(acc[i][j][r] + bias, 0.f);
+                for (int r = 0; r < 4; ++r) xs[(wr * (ROWS / 2) + i * 16 + fq * 4 + r) * kChainXld + col] = fmaxf(acc[i][j][r] + bias, 0.f);
         }
         float w2[64];                                  // dense2 as B operands, the head kernel's packing (chain_pack_layer)
 #pragma unroll
         for (int i = 0; i < 64; ++i) w2[i] = w2pack[i * 64 + lane];
         const float b2 = w2pack[64 * 64 + 16 * 64 + fr];
         __syncthreads();
-        f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wv < ROWS / 16) {      // (64-row tiles: waves 0 .. 3; wave-uniform)
+            f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 64; ++i)
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(wv * 16 + fr) * kChainXld + 4 * i + fq], w2[i], a2, 0, 0, 0);
-        f32x4 z;
+            for (int i = 0; i < 64; ++i)
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(wv * 16 + fr) * kChainXld + 4 * i + fq], w2[i], a2, 0, 0, 0);
+            f32x4 z;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[r] = a2[r] + b2;
-        chain_softmax_store(z, fr, fq, row0 + wv * 16, n, n_out, probs, labels, nullptr);
+            for (int r = 0; r < 4; ++r) z[r] = a2[r] + b2;
+            chain_softmax_store(z, fr, fq, row0 + wv * 16, n, n_out, probs, labels, nullptr);
+        }
     }
 }
 
@@ -616,15 +628,18 @@ static int vtcnn2_run(const mdc_model* m, const float* x, long hop2, float scale
 #ifdef MDC_ALTERNATES
                 if (m->alt & kAltSeparateHead) fuse = false;
 #endif
-                const dim3 grid((unsigned)((n + kDM - 1) / kDM));
+#define MDC_LAUNCH_D1F32(H, R) do { \
+                    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_f32_kernel<H, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense1_f32_lds<R>())); \
+                    hipLaunchKernelGGL((vt_dense1_f32_kernel<H, R>), dim3((unsigned)((n + R - 1) / R)), dim3(512), dense1_f32_lds<R>(), s, featf, (long)n, w1p, c1, hid, \
+                                       w2pack, C, probs, labels); } while (0)
+                const bool half = n <= 16384;      // at most 256 tiles of 64 rows: every tile on its own CU
                 if (fuse) {
-                    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDense1F32Lds));
-                    hipLaunchKernelGGL(vt_dense1_f32_kernel<true>, grid, dim3(512), kDense1F32Lds, s, featf, (long)n, w1p, c1, hid, w2pack, C, probs, labels);
+                    if (half) MDC_LAUNCH_D1F32(true, 64); else MDC_LAUNCH_D1F32(true, 128);
                     head_done = true;
                 } else {
-                    MDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vt_dense1_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDense1F32Lds));
-                    hipLaunchKernelGGL(vt_dense1_f32_kernel<false>, grid, dim3(512), kDense1F32Lds, s, featf, (long)n, w1p, c1, hid, w2pack, C, probs, labels);
+                    if (half) MDC_LAUNCH_D1F32(false, 64); else MDC_LAUNCH_D1F32(false, 128);
                 }
+#undef MDC_LAUNCH_D1F32
             }
             MDC_HIP(hipGetLastError());
         }

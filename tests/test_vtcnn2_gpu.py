@@ -240,10 +240,13 @@ def test_small_batch_forms_are_bit_identical_to_the_batch_kernels(dtype):
     not depend on how many frames it arrives with.  (The reference classifies one window per start pulse,
     cnn_test_latest1.sv:144-209.)"""
     m, _ = _model(11, dtype)
-    x = synthetic_frames(9000, seed=31, device="cuda")
-    big_p, big_l, _ = m.forward_device(x, batch_size=9000)            # batch kernels (n > 8,192)
-    big_h = m.predict(x, tap="hidden", batch_size=9000)
-    for n in (1, 2, 15, 16, 17, 33, 64, 65, 128, 129, 300, 1009, 1024, 1025, 2048, 2049, 4097, 8192, 8193):      # every launch form and its boundaries
+    # f32 (round 5): dense1 takes 64-row tiles up to 16,384 frames and 128-row tiles beyond -- the big batch is the 128-row form
+    nbig = 20000 if dtype == "f32" else 9000
+    x = synthetic_frames(nbig, seed=31, device="cuda")
+    big_p, big_l, _ = m.forward_device(x, batch_size=nbig)            # batch kernels (n > 8,192; f32: > 16,384)
+    big_h = m.predict(x, tap="hidden", batch_size=nbig)
+    sizes = (1, 2, 15, 16, 17, 33, 64, 65, 128, 129, 300, 1009, 1024, 1025, 2048, 2049, 4097, 8192, 8193) + ((16384, 16385) if dtype == "f32" else ())
+    for n in sizes:      # every launch form and its boundaries
         xs = x[:n].contiguous()
         p, l, _ = m.forward_device(xs)
         assert torch.equal(p, big_p[:n]) and torch.equal(l, big_l[:n]), (dtype, n)
