@@ -31,10 +31,18 @@ namespace mdc {
 
 namespace {
 
-// async global -> LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16
+// async global -> LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16.  Issued from asm (round 5): hipcc
+// tracks the BUILTIN form as an LDS store it cannot tell apart from the buffer being read, and put an s_waitcnt vmcnt(0) right
+// behind the prefetch of the next weight chunk, in front of the first LDS read of the current one (ISA of rounds 1-4: the
+// "double buffer" drained at the start of every chunk).  The kernel's own waits order both ways: vmcnt(0) in front of the barrier
+// that ends a chunk (the next chunk has landed before anyone reads it), and that same barrier before a buffer is refilled.
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+    asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(g), "{m0}"(l) : "memory");
+}
+__device__ __forceinline__ void glds_drain_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------
@@ -100,12 +108,15 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
     }
     // ---- chunk 0 of the conv2 weights: LDS-DMA, 30 pieces of 1 KiB, piece p by wave p%4 ----
     for (int p = q; p < kWChunkFloats / 256; p += 4) glds16(wpack + p * 256 + lane * 4, wbuf + p * 256);
-    __syncthreads();
+    glds_drain_and_barrier();
 
     const float* xrow0 = xw + (0 * 16 + nl) * kXld + g;    // lane reads xp[n][h][v + g]
     const float* xrow1 = xw + (1 * 16 + nl) * kXld + g;
 
     int it = 0;
+    // conv1's A operand of the NEXT chunk is fetched one chunk ahead as well: a plain load issued behind the LDS-DMA would make
+    // hipcc's wait for it (vmcnt(0): loads return in order) a wait for the whole prefetch
+    float a1n = a1pack[lane];
     constexpr int kNPB = kW2 / KP;
     static_assert(kNPB * KP == kW2, "KP must divide 132");
     for (int pb = YSPLIT ? (int)blockIdx.y : 0; pb < (YSPLIT ? (int)blockIdx.y + 1 : kNPB); ++pb) {
@@ -127,7 +138,8 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
                 float* dst = wbuf + ((it + 1) & 1) * kWChunkFloats;
                 for (int p = q; p < kWChunkFloats / 256; p += 4) glds16(src + p * 256 + lane * 4, dst + p * 256);
             }
-            const float a1 = a1pack[cc * 64 + lane];   // conv1 A operand: K1[c][g] (g<3) | b1[c] (g=3)
+            const float a1 = a1n;                      // conv1 A operand: K1[c][g] (g<3) | b1[c] (g=3)
+            a1n = a1pack[((cc + 1) & (kNChunk - 1)) * 64 + lane];
 #pragma unroll
             for (int u = 0; u < KP + 2; ++u) {
                 const int wp = w0 + u;                 // padded position w' of y1p
@@ -154,8 +166,8 @@ __global__ __launch_bounds__(256, 1) void vt_conv_f32_kernel(const float* __rest
                     }
                 }
             }
-            // __syncthreads() drains the LDS-DMA (vmcnt(0)) before the barrier
-            __syncthreads();
+            // the next chunk has landed (this wave's pieces: vmcnt(0)), then everybody's (barrier)
+            glds_drain_and_barrier();
         }
         // ---- epilogue of the block: bias, ReLU, store feat[frame][w][o] ----
         const long f = frame0 + nl;
