@@ -288,6 +288,19 @@ MDC_API int mdc_trainer_layer_sizes(const mdc_trainer* t, int layer, size_t* ker
  * means and what every bundled .h5's training_config records) hold until this is called. */
 MDC_API int mdc_trainer_set_adam(mdc_trainer* t, float lr, float beta1, float beta2, float eps);
 
+/* OPTIONAL Dropout(rate), off by default (rate 0 = the nets as the reference defines them: cnn.py:104-112 and CNN.ipynb cell 6
+ * contain no Dropout layer; their `dr = 0.5` / `0.6` is left over from the DeepSig definition, which has `model.add(Dropout(dr))`
+ * behind every conv and behind dense1 -- RML2016.10a_VTCNN2_example.ipynb:229-243).  With rate > 0 the training batches
+ * (mdc_train_batch, either value of `apply`) multiply the conv + ReLU output -- and, for MDC_KIND_CNNPY, the Dense(D, relu)
+ * output -- by mask / (1 - rate), Keras' Dropout; mdc_trainer_evaluate and every mdc_forward* never do (inference).  TensorFlow's
+ * generator cannot be replayed, so the mask comes from a stated counter-based one (uint32 arithmetic):
+ *     fmix32(h):  h ^= h >> 16;  h *= 0x85EBCA6B;  h ^= h >> 13;  h *= 0xC2B2AE35;  h ^= h >> 16
+ *     k_step  = fmix32(seed + 0x9E3779B9 * (iterations + 1))          iterations: Adam's step count (on the device)
+ *     k_frame = fmix32(k_step ^ (frame * 0x85EBCA6B + site))          frame: the frame's index in x_dev; site 0 conv, 1 dense
+ *     keep element e (its index in the layer's Flatten order) iff fmix32(k_frame + e * 0xC2B2AE35) >= floor(rate * 2^32)
+ * -- a new mask at every step (also under hipGraph replay), the same mask for a frame whatever batch it arrives in. */
+MDC_API int mdc_trainer_set_dropout(mdc_trainer* t, float rate, uint32_t seed);
+
 /* Per-layer tensors in the layouts of mdc_set_weights.  MDC_TRAIN_WEIGHTS must be set for every layer before the first
  * batch; Adam's moments start at zero and `iterations` at 0 (set them to resume from a full-model .h5, whose
  * /optimizer_weights group holds exactly these).  MDC_TRAIN_GRADIENT (get only): d(mean loss)/d(weights) of the last

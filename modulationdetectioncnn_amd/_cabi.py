@@ -26,7 +26,7 @@ EXPORTS = [
     "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax",
     "mdc_forward_iq_u8", "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8",
     "mdc_crossentropy", "mdc_set_fp8_feature_absmax",
-    "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_tensor",
+    "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_dropout", "mdc_trainer_set_tensor",
     "mdc_trainer_get_tensor", "mdc_trainer_set_iterations", "mdc_train_batch", "mdc_trainer_evaluate", "mdc_trainer_read",
     "mdc_trainer_destroy",
 ]
@@ -103,6 +103,7 @@ def lib(variant: str = "product") -> C.CDLL:
     L.mdc_trainer_num_layers.argtypes = [vp]
     L.mdc_trainer_layer_sizes.argtypes = [vp, i32, C.POINTER(sz), C.POINTER(sz)]
     L.mdc_trainer_set_adam.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.mdc_trainer_set_dropout.argtypes = [vp, C.c_float, C.c_uint32]
     L.mdc_trainer_set_tensor.argtypes = [vp, i32, i32, fp, sz, fp, sz, vp]
     L.mdc_trainer_get_tensor.argtypes = [vp, i32, i32, fp, sz, fp, sz, vp]
     L.mdc_trainer_set_iterations.argtypes = [vp, i64, vp]
@@ -115,7 +116,7 @@ def lib(variant: str = "product") -> C.CDLL:
                  "mdc_forward", "mdc_set_profiling", "mdc_profile_slots", "mdc_profile_read", "mdc_profile_reset",
                  "mdc_forward_q612", "mdc_confusion", "mdc_iq_u8_to_frames", "mdc_set_fp8_input_absmax", "mdc_forward_iq_u8",
                  "mdc_confusion_binned", "mdc_iq_u8_windows", "mdc_predict_host", "mdc_predict_host_iq_u8", "mdc_crossentropy", "mdc_set_fp8_feature_absmax",
-                 "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_tensor",
+                 "mdc_trainer_create", "mdc_trainer_num_layers", "mdc_trainer_layer_sizes", "mdc_trainer_set_adam", "mdc_trainer_set_dropout", "mdc_trainer_set_tensor",
                  "mdc_trainer_get_tensor", "mdc_trainer_set_iterations", "mdc_train_batch", "mdc_trainer_evaluate", "mdc_trainer_read"):
         getattr(L, name).restype = i32
     if L.mdc_abi_version() != ABI_VERSION:

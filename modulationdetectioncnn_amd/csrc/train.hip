@@ -3,8 +3,12 @@
 //     model.fit(X_train, Y_train, batch_size=1024, epochs=100, validation_data=..., callbacks=[ModelCheckpoint,
 //               EarlyStopping])                                                              cnn.py:122-147, CNN.ipynb cell 8
 // for MDC_KIND_DEPLOYED (CNN.ipynb cell 6: T1 F=3 / T2 F=10) and MDC_KIND_CNNPY (cnn.py:104-112: T4), in f32.  Neither net
-// has a Dropout layer (`dr` is never used in them), so the training forward IS the inference forward.  The canonical
-// VT-CNN2 (T3) is trained only in the vendored DeepSig notebook: out of scope.
+// has a Dropout layer (`dr` is never used in them), so the training forward IS the inference forward -- unless the caller
+// asks for one (mdc_trainer_set_dropout; off by default): inverted Dropout(rate) behind the conv activations (and behind
+// cnn.py's Dense(D)), where VT-CNN2 has it, its mask a pure function of (seed, Adam's step count, the frame's index in the
+// data set, the element) through murmur3's 32-bit finaliser -- no generator state, so the backward pass, a replayed
+// hipGraph and the numpy oracle all see the same bits.  The canonical VT-CNN2 (T3) is trained only in the vendored DeepSig
+// notebook: out of scope.
 //
 // One mini-batch = two launches on the caller's stream, no host synchronisation, nothing allocated:
 //   mdc_train_grad   one wave per slice of the batch (frames g, g+G, ...): forward, Keras' categorical cross-entropy on
@@ -21,12 +25,13 @@
 //                    a step is reproducible bit for bit; G = count / 2, or / 4 for the 10-filter net, at most 1,024),
 //                    scales by 1/count (gradient of the MEAN loss), and applies
 //                    TensorFlow 2.4's Adam: alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1); v += (g*g-v)(1-b2);
-//                    w -= m*alpha/(sqrt(v)+eps).  t lives on the device (incremented by the gradient kernel), so a
-//                    captured hipGraph of an epoch replays correctly.
+//                    w -= m*alpha/(sqrt(v)+eps).  t lives on the device (the last work-group of this launch to
+//                    finish bumps it, after all have read it), so a captured hipGraph of an epoch replays correctly.
 // The batch of the reference (1,024 frames x 2,334 parameters) is launch-latency bound on this chip; that is why a step
 // is two launches and an epoch needs no host round trip but the final read of the loss.
 #include "dense_chain_common.h"      // mdc_internal.h, f32x4, row_allreduce (the 16-lane DPP butterflies of the softmax head)
 
+#include <cmath>
 #include <cstddef>
 #include <cstring>
 #include <new>
@@ -41,6 +46,8 @@ struct mdc_trainer {
     size_t P = 0;
     bool have[4]{};
     float lr = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f;      // keras.optimizers.Adam() defaults = the .h5 files' training_config
+    float drop_rate = 0.f;       // optional Dropout(rate) behind the conv activations (and cnn.py's Dense(D)): 0 = the reference's nets
+    unsigned drop_seed = 0;
     // device state
     float* d_params = nullptr;   // [P] master weights
     float* d_m = nullptr;        // [P] Adam first moment
@@ -61,12 +68,33 @@ constexpr int kMaxWaves = 1024;      // partial gradient vectors per batch
 constexpr float kKerasEps = 1e-7f;   // K.epsilon()
 
 struct TrainState {
-    long long iterations;      // Adam's `iter` (optimizer_weights/Adam/iter:0 of the .h5)
+    long long iterations;      // Adam's `iter` (optimizer_weights/Adam/iter:0 of the .h5): completed updates
     long long train_frames;
     double train_loss;         // sum over frames of the per-sample loss since the last read (fit's running epoch loss)
     long long eval_frames;
     double eval_loss;
+    unsigned tickets;          // work-groups of the running reduce + Adam launch that have read `iterations` (the last one bumps it)
+    unsigned pad_;
 };
+
+// The optional Dropout's counter-based generator (include/mdc.h, mdc_trainer_set_dropout; oracle/oracle_train.py restates it):
+// keep an element iff fmix32(k_frame + element * 0xC2B2AE35) >= thr, k_frame = fmix32(k_step ^ (frame * 0x85EBCA6B + site)),
+// k_step = fmix32(seed + 0x9E3779B9 * (step + 1)); step = Adam's iteration count, read from the device (a replayed hipGraph
+// draws new masks at every step), frame = the frame's index in the data set (a frame's mask does not depend on its batch).
+struct DropArgs { unsigned seed, thr; float inv; };
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ unsigned drop_step_key(const DropArgs& d, const TrainState* st) {
+    return fmix32(d.seed + 0x9E3779B9u * (unsigned)(st->iterations + 1));
+}
+__device__ __forceinline__ unsigned drop_frame_key(unsigned kstep, long frame, unsigned site) {
+    return fmix32(kstep ^ ((unsigned)frame * 0x85EBCA6Bu + site));
+}
+__device__ __forceinline__ bool drop_keep(unsigned kframe, unsigned element, unsigned thr) {
+    return fmix32(kframe + element * 0xC2B2AE35u) >= thr;
+}
 
 __device__ __forceinline__ float wave_allsum(float v) {
 #pragma unroll
@@ -107,11 +135,11 @@ __device__ __forceinline__ float softmax_xent(const float (&d)[CMAX], const floa
 // ---- deployed net (CNN.ipynb cell 6): lane = (row h = lane>>5, positions w = 4l'..4l'+3, l' = lane&31; lane l' = 31 also w = 128)
 // WLDS: the lane's 5 x F x 3 dense weights live in LDS ([entry][lane]: conflict-free) instead of registers -- the gradient
 // kernel of the 10-filter net would otherwise hold 150 weights + 150 gradient sums per lane and spill.
-template <int F, bool GRAD, bool WLDS>
+template <int F, bool GRAD, bool WLDS, bool DROP = false>
 __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const int* __restrict__ order, long first, int count,
                                                            const float* __restrict__ params, float* __restrict__ partials,
-                                                           double* __restrict__ loss_partials, TrainState* __restrict__ st, int bump_iter) {
+                                                           double* __restrict__ loss_partials, const TrainState* __restrict__ st, DropArgs drop) {
     constexpr int C = 3, S = 5;
     constexpr int offCb = 2 * F, offWd = 3 * F, offBd = 3 * F + 258 * F * C, P = offBd + C;
     __shared__ float sW[WLDS ? S * F * C * 64 : 1];
@@ -145,11 +173,14 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < C; ++c) gbd[c] = 0.f;
     double loss = 0.0;
+    const unsigned kstep = DROP ? drop_step_key(drop, st) : 0u;
 
     // the next frame's samples and targets are loaded while this frame is computed (a wave walks its frames one at a time;
     // the sched_barrier keeps hipcc from sinking the loads to their first use)
+    long idx_n = 0;
     auto fetch = [&](int i, float4& xv, float (&yv)[C]) {
         const long idx = order ? (long)order[first + i] : first + i;
+        idx_n = idx;
         xv = *reinterpret_cast<const float4*>(x + idx * kFrameFloats + h * kSamples + 4 * lp);
 #pragma unroll
         for (int c = 0; c < C; ++c) yv[c] = y[idx * C + c];
@@ -160,11 +191,26 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
     for (int i = g; i < count; i += G) {
         if (WLDS) asm volatile("" ::: "memory");      // keep the LDS weight reads inside the loop (hoisted, they are 150 registers again)
         const float4 xv = xn;
+        const long idx_cur = idx_n;
         float yv[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) yv[c] = yn[c];
         if (i + G < count) fetch(i + G, xn, yn);
         __builtin_amdgcn_sched_barrier(0);
+        // Dropout behind the conv activations: one keep bit per (slot, filter) of this lane, element = the Flatten index
+        unsigned long long keep = ~0ull;
+        if (DROP) {
+            const unsigned kf = drop_frame_key(kstep, idx_cur, 0u);
+            keep = 0ull;
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const unsigned e = (unsigned)((h * 129 + (s < 4 ? 4 * lp + s : 128)) * F + f);
+                    if (drop_keep(kf, e, drop.thr)) keep |= 1ull << (s * F + f);
+                }
+        }
+        auto scale_of = [&](int s, int f) -> float { return DROP ? (((keep >> (s * F + f)) & 1ull) ? drop.inv : 0.f) : 1.f; };
         float xprev = __shfl_up(xv.w, 1, 64);
         if (lp == 0) xprev = 0.f;                                       // ZeroPadding2D((0,1)): x[h][-1] = 0
         const float xin[S] = {xprev, xv.x, xv.y, xv.z, xv.w};           // x[h][w-1]
@@ -174,7 +220,8 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                const float a = fmaxf(fmaf(k1[f], xcu[s], k0[f] * xin[s]) + cb[f], 0.f);
+                float a = fmaxf(fmaf(k1[f], xcu[s], k0[f] * xin[s]) + cb[f], 0.f);
+                if (DROP) a *= scale_of(s, f);
 #pragma unroll
                 for (int c = 0; c < C; ++c) z[c] = fmaf(a, Wv(s, f, c), z[c]);
             }
@@ -191,10 +238,12 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
                     const float pre = fmaf(k1[f], xcu[s], k0[f] * xin[s]) + cb[f];
-                    const float a = fmaxf(pre, 0.f);
+                    float a = fmaxf(pre, 0.f);
+                    if (DROP) a *= scale_of(s, f);
                     float da = 0.f;
 #pragma unroll
                     for (int c = 0; c < C; ++c) { da = fmaf(Wv(s, f, c), gz[c], da); dW[s][f][c] = fmaf(a, gz[c], dW[s][f][c]); }
+                    if (DROP) da *= scale_of(s, f);
                     const float dpre = pre > 0.f ? da : 0.f;            // (W = 0 in the slots a lane does not own: da = 0 there)
                     gk0[f] = fmaf(dpre, xin[s], gk0[f]);
                     gk1[f] = fmaf(dpre, xcu[s], gk1[f]);
@@ -222,7 +271,6 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < C; ++c) out[offBd + c] = gbd[c];
-        if (bump_iter && g == 0) st->iterations += 1;      // the Adam launch behind this one on the stream reads t = iterations
     }
 }
 
@@ -244,11 +292,11 @@ constexpr int kT4Mc = 0, kT4Cb = 256 * 32, kT4W1 = kT4Cb + 32, kT4B1 = kT4W1 + 3
               kT4Pint = kT4B2 + 16;              // 9,024 floats per partial
 constexpr int kT4Xld = kChainXld, kT4Yld = 36;
 
-template <bool GRAD>
+template <bool GRAD, bool DROP = false>
 __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ order,
                                                         long first, int count, int F, int D, int C, const float* __restrict__ params,
                                                         float* __restrict__ partials, double* __restrict__ loss_partials,
-                                                        TrainState* __restrict__ st, int bump_iter) {
+                                                        const TrainState* __restrict__ st, DropArgs drop) {
     const int A = 3 * F;
     const int offCb = 256 * F, offW1 = offCb + F, offB1 = offW1 + A * D, offW2 = offB1 + D, offB2 = offW2 + D * C;
     __shared__ __attribute__((aligned(16))) float xs[16 * kT4Xld];
@@ -294,6 +342,7 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
     }
     dW1a[0] = dW1a[1] = dW2a = f32x4{0.f, 0.f, 0.f, 0.f};
     double loss = 0.0;
+    const unsigned kstep = DROP ? drop_step_key(drop, st) : 0u;
 
     const int ntiles = (count + 15) >> 4;
     for (int tile = blockIdx.x; tile < ntiles; tile += G) {
@@ -309,12 +358,22 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
             *reinterpret_cast<float4*>(xs + r * kT4Xld + 4 * lane) = v;
         }
         // targets in the C/D layout: lane (class fr, rows 4g + r); zero rows past the end contribute nothing anywhere below
-        float yv[4];
+        float yv[4], m0[2][4], m1[4];      // targets; Dropout scales of the lane's conv activations (site 0) and hidden units (site 1)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int fi = f0 + 4 * g + r;
             yv[r] = 0.f;
-            if (cls && fi < count) { const long idx = order ? (long)order[first + fi] : first + fi; yv[r] = y[idx * C + fr]; }
+            m0[0][r] = m0[1][r] = m1[r] = 1.f;
+            if (fi < count) {
+                const long idx = order ? (long)order[first + fi] : first + fi;
+                if (cls) yv[r] = y[idx * C + fr];
+                if (DROP) {
+                    const unsigned k0f = drop_frame_key(kstep, idx, 0u), k1f = drop_frame_key(kstep, idx, 1u);
+                    m0[0][r] = drop_keep(k0f, (unsigned)fr, drop.thr) ? drop.inv : 0.f;
+                    m0[1][r] = drop_keep(k0f, (unsigned)(16 + fr), drop.thr) ? drop.inv : 0.f;
+                    m1[r] = drop_keep(k1f, (unsigned)fr, drop.thr) ? drop.inv : 0.f;
+                }
+            }
         }
         __syncthreads();
         // ---- forward
@@ -332,6 +391,7 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
             for (int r = 0; r < 4; ++r) {
                 pre[jt][r] = acc[jt][r] + cbv[jt];
                 a1[jt][r] = fmaxf(pre[jt][r], 0.f);
+                if (DROP) a1[jt][r] *= m0[jt][r];
                 ys[(4 * g + r) * kT4Yld + 16 * jt + fr] = a1[jt][r];
             }
         __syncthreads();
@@ -341,7 +401,12 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
         f32x4 h;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { z1[r] += b1v; h[r] = fmaxf(z1[r], 0.f); ys[(4 * g + r) * kT4Yld + fr] = h[r]; }      // Dense(D, relu)
+        for (int r = 0; r < 4; ++r) {      // Dense(D, relu)
+            z1[r] += b1v;
+            h[r] = fmaxf(z1[r], 0.f);
+            if (DROP) h[r] *= m1[r];
+            ys[(4 * g + r) * kT4Yld + fr] = h[r];
+        }
         __syncthreads();
         f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -378,7 +443,7 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) dz1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kT4Yld + 4 * i + g], W2t[i], dz1, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz1[r] = z1[r] > 0.f ? dz1[r] : 0.f;
+            for (int r = 0; r < 4; ++r) dz1[r] = z1[r] > 0.f ? (DROP ? dz1[r] * m1[r] : dz1[r]) : 0.f;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -395,7 +460,7 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
 #pragma unroll
                 for (int i = 0; i < 4; ++i) da = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[fr * kT4Yld + 4 * i + g], W1t[jt][i], da, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dpre[jt][r] = pre[jt][r] > 0.f ? da[r] : 0.f;
+                for (int r = 0; r < 4; ++r) dpre[jt][r] = pre[jt][r] > 0.f ? (DROP ? da[r] * m0[jt][r] : da[r]) : 0.f;
                 gcb[jt] += (dpre[jt][0] + dpre[jt][1]) + (dpre[jt][2] + dpre[jt][3]);
             }
 #pragma unroll
@@ -431,7 +496,6 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
     auto over_g = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
     const float c0 = over_g(gcb[0]), c1 = over_g(gcb[1]), s1 = over_g(gb1), s2 = over_g(gb2);
     if (g == 0) { out[kT4Cb + fr] = c0; out[kT4Cb + 16 + fr] = c1; out[kT4B1 + fr] = s1; out[kT4B2 + fr] = s2; }
-    if (lane == 0 && bump_iter && blockIdx.x == 0) st->iterations += 1;
 }
 
 // ---- fixed-order reduction of the partials + TensorFlow 2.4's Adam.  Block = 64 parameters x 16 slices of the G partials: a
@@ -449,6 +513,7 @@ __global__ __launch_bounds__(1024) void train_adam_kernel(const float* __restric
     __shared__ double lpart[1024];
     const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
+    const long long it0 = st->iterations;      // every thread reads it before its work-group takes a ticket (below)
     if (mode != 0) {
         float acc = 0.f;
         if (i < P) {
@@ -479,7 +544,7 @@ __global__ __launch_bounds__(1024) void train_adam_kernel(const float* __restric
             const float gmean = gsum / (float)count;
             grad[i] = gmean;
             if (mode == 2) {
-                const float t = (float)st->iterations;      // already incremented by the gradient launch
+                const float t = (float)(it0 + 1);            // this update's number; `iterations` is bumped by the last work-group to finish
                 const float alpha = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
                 const float mi = m[i] + (gmean - m[i]) * (1.f - beta1);
                 const float vi = v[i] + (gmean * gmean - v[i]) * (1.f - beta2);
@@ -499,6 +564,18 @@ __global__ __launch_bounds__(1024) void train_adam_kernel(const float* __restric
         if (threadIdx.x == 0) {
             if (mode == 0) { st->eval_loss += lpart[0]; st->eval_frames += count; }
             else { st->train_loss += lpart[0]; st->train_frames += count; }
+        }
+    }
+    if (mode == 2) {
+        // Adam's step count advances ONCE, after every work-group of this launch has read it: the gradient kernels only ever read
+        // it (their Dropout masks are keyed by it), so it is stable for the whole of the next launch
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(&st->tickets, 1u) == gridDim.x - 1) {
+                st->tickets = 0u;
+                st->iterations = it0 + 1;
+            }
         }
     }
 }
@@ -574,22 +651,31 @@ int waves_for(const mdc_trainer* t, int64_t count) {
 int launch_batch(mdc_trainer* t, const float* x, const float* y, const int32_t* order, int64_t first, int64_t count, int mode, hipStream_t s) {
     const int G = waves_for(t, count);
     auto* st = static_cast<TrainState*>(t->d_state);
-    const int bump = mode == 2 ? 1 : 0;
     const int cnt = (int)count;
+    // Dropout acts in training batches only (mode != 0: Keras' fit reports the loss WITH it, evaluates val_loss without)
+    const bool drop_on = mode != 0 && t->drop_rate > 0.f;
+    const DropArgs drop{t->drop_seed, (unsigned)std::floor((double)t->drop_rate * 4294967296.0), 1.f / (1.f - t->drop_rate)};
+#define MDC_TRAIN_DEP(F, GR, WL, DR) hipLaunchKernelGGL((train_deployed_kernel<F, GR, WL, DR>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, \
+                                                         t->d_params, t->d_partials, t->d_loss_partials, st, drop)
+#define MDC_TRAIN_T4(GR, DR) hipLaunchKernelGGL((train_cnnpy_kernel<GR, DR>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->topo.filters, \
+                                                 t->topo.hidden, t->topo.classes, t->d_params, t->d_partials, t->d_loss_partials, st, drop)
     if (t->topo.kind == MDC_KIND_DEPLOYED) {
         if (t->topo.filters == 3) {
-            if (mode) hipLaunchKernelGGL((train_deployed_kernel<3, true, false>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
-            else      hipLaunchKernelGGL((train_deployed_kernel<3, false, false>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+            if (!mode) MDC_TRAIN_DEP(3, false, false, false);
+            else if (drop_on) MDC_TRAIN_DEP(3, true, false, true);
+            else MDC_TRAIN_DEP(3, true, false, false);
         } else {
-            if (mode) hipLaunchKernelGGL((train_deployed_kernel<10, true, true>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
-            else      hipLaunchKernelGGL((train_deployed_kernel<10, false, false>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+            if (!mode) MDC_TRAIN_DEP(10, false, false, false);
+            else if (drop_on) MDC_TRAIN_DEP(10, true, true, true);
+            else MDC_TRAIN_DEP(10, true, true, false);
         }
     } else {
-        if (mode) hipLaunchKernelGGL(train_cnnpy_kernel<true>, dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->topo.filters, t->topo.hidden, t->topo.classes,
-                                     t->d_params, t->d_partials, t->d_loss_partials, st, bump);
-        else      hipLaunchKernelGGL(train_cnnpy_kernel<false>, dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->topo.filters, t->topo.hidden, t->topo.classes,
-                                     t->d_params, t->d_partials, t->d_loss_partials, st, bump);
+        if (!mode) MDC_TRAIN_T4(false, false);
+        else if (drop_on) MDC_TRAIN_T4(true, true);
+        else MDC_TRAIN_T4(true, false);
     }
+#undef MDC_TRAIN_DEP
+#undef MDC_TRAIN_T4
     MDC_HIP(hipGetLastError());
     const int P = (int)t->P;
     const int blocks = mode == 0 ? 1 : (P + 63) / 64;
@@ -683,6 +769,14 @@ int mdc_trainer_set_adam(mdc_trainer* t, float lr, float beta1, float beta2, flo
         return MDC_EINVAL;
     }
     t->lr = lr; t->beta1 = beta1; t->beta2 = beta2; t->eps = eps;
+    return MDC_OK;
+}
+
+int mdc_trainer_set_dropout(mdc_trainer* t, float rate, uint32_t seed) {
+    if (!t) { set_error("null trainer"); return MDC_EINVAL; }
+    if (!(rate >= 0.f && rate < 1.f)) { set_error("mdc_trainer_set_dropout: need 0 <= rate < 1"); return MDC_EINVAL; }
+    t->drop_rate = rate;
+    t->drop_seed = seed;
     return MDC_OK;
 }
 

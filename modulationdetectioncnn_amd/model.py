@@ -188,12 +188,14 @@ class VTCNN2:
 
     # ------------------------------------------------------------------ training (cnn.py:113, 122-147)
     def compile(self, loss: str = "categorical_crossentropy", optimizer: str = "adam", lr: float = 1e-3, beta1: float = 0.9,
-                beta2: float = 0.999, eps: float = 1e-7) -> None:
+                beta2: float = 0.999, eps: float = 1e-7, dropout: float = 0.0, dropout_seed: int = 0) -> None:
         """``model.compile(loss='categorical_crossentropy', optimizer='adam')`` (cnn.py:113): the one loss and the one
-        optimizer the reference uses; the keyword arguments are keras.optimizers.Adam's (its defaults)."""
+        optimizer the reference uses; the keyword arguments are keras.optimizers.Adam's (its defaults).  dropout: the optional
+        Dropout(dr) of the DeepSig definition behind the conv activations (training batches only; 0 = the reference's nets)."""
         if loss != "categorical_crossentropy" or str(optimizer).lower() != "adam":
             raise ValueError("the reference compiles with loss='categorical_crossentropy', optimizer='adam'; nothing else is built")
-        self._adam = dict(lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps))
+        self._adam = dict(lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps), dropout=float(dropout),
+                          dropout_seed=int(dropout_seed))
         self._drop_trainer()
 
     def _drop_trainer(self) -> None:
@@ -235,7 +237,7 @@ class VTCNN2:
             raise RuntimeError("no weights loaded")
         t = getattr(self, "_trainer", None)
         write_keras_h5(filepath, self.topology, self._weights, optimizer=t.optimizer_state() if t is not None else None,
-                       adam=getattr(self, "_adam", None) or {})
+                       adam={k: v for k, v in (getattr(self, "_adam", None) or {}).items() if not k.startswith("dropout")})
 
     # ------------------------------------------------------------------ engine
     def _lib(self):

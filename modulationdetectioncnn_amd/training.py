@@ -65,7 +65,11 @@ class Trainer:
     """The compiled model's training state on one MI355X: f32 master weights, Adam moments, step count."""
 
     def __init__(self, topology: Topology, weights: Sequence[Tuple[np.ndarray, np.ndarray]], device: Optional[int] = None,
-                 lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7, _lib_variant: str = "product"):
+                 lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7, dropout: float = 0.0,
+                 dropout_seed: int = 0, _lib_variant: str = "product"):
+        """dropout: OPTIONAL Dropout(rate) behind the conv activations (and cnn.py's Dense(10)) in training batches -- 0, the
+        default, is the reference's nets, which contain no Dropout layer (mdc_trainer_set_dropout in include/mdc.h states the
+        counter-based mask generator)."""
         if topology.kind not in ("deployed", "cnnpy"):
             raise ValueError("the reference trains the deployed (CNN.ipynb cell 6) and cnn.py (cnn.py:104-112) nets; "
                              f"training is not built for {topology.kind!r}")
@@ -81,6 +85,9 @@ class Trainer:
         self._check(L.mdc_trainer_create(C.byref(topo), self.device_index, C.byref(self._h)))
         self.adam = dict(lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps))
         self._check(L.mdc_trainer_set_adam(self._h, *[self.adam[k] for k in ("lr", "beta1", "beta2", "eps")]))
+        self.dropout, self.dropout_seed = float(dropout), int(dropout_seed) & 0xFFFFFFFF
+        if self.dropout:
+            self._check(L.mdc_trainer_set_dropout(self._h, self.dropout, self.dropout_seed))
         self._set(_cabi.TRAIN_WEIGHTS, weights)
 
     # ------------------------------------------------------------------ plumbing

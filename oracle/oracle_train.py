@@ -71,8 +71,45 @@ def _softmax_backward(p, gp):
     return p * (gp - (gp * p).sum(axis=-1, keepdims=True))
 
 
-def loss_and_grads_deployed(x, y, weights: Weights, dtype=np.float64):
-    """CNN.ipynb cell 6 net: returns (mean loss, per-sample losses, [(dkernel, dbias)] of the MEAN loss, probs)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# Optional Dropout(dr) behind the conv activations (and behind cnn.py's Dense(10)) -- the positions the reference's `dr` was
+# written for: the DeepSig notebook it derives from has `model.add(Dropout(dr))` after every conv and after dense1
+# (RML2016.10a_VTCNN2_example.ipynb:229-243); the reference's own definitions (cnn.py:104-112, CNN.ipynb cell 6) dropped those
+# layers and kept the variable.  Keras: training output = x * mask / (1 - rate), mask ~ Bernoulli(1 - rate) per element and
+# step; inference: identity.  TensorFlow's generator cannot be replayed, so the library uses a STATED counter-based one
+# (include/mdc.h, mdc_trainer_set_dropout), restated here bit for bit:
+#     fmix32(h):  h ^= h >> 16;  h *= 0x85EBCA6B;  h ^= h >> 13;  h *= 0xC2B2AE35;  h ^= h >> 16        (murmur3's finaliser)
+#     k_step  = fmix32(seed + 0x9E3779B9 * (step + 1))            step = Adam's iteration count before this update
+#     k_frame = fmix32(k_step ^ (frame * 0x85EBCA6B + site))      frame = the frame's index in the data set, site 0 conv / 1 dense1
+#     u       = fmix32(k_frame + element * 0xC2B2AE35)            element = index in the layer's Flatten order
+#     keep iff u >= floor(rate * 2^32)
+# ---------------------------------------------------------------------------------------------------------------------
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _fmix32(h):
+    h = np.asarray(h, np.uint64) & _M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & _M32
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & _M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def dropout_scale(rate: float, seed: int, step: int, frames, nelem: int, site: int, dtype=np.float64) -> np.ndarray:
+    """(len(frames), nelem) array of 0 or 1 / (1 - rate): what the kernels multiply the layer's output by."""
+    frames = np.asarray(frames, np.uint64) & _M32
+    k_step = _fmix32((np.uint64(seed) + np.uint64(0x9E3779B9) * np.uint64(step + 1)) & _M32)
+    k_frame = _fmix32(k_step ^ ((frames * np.uint64(0x85EBCA6B) + np.uint64(site)) & _M32))
+    u = _fmix32((k_frame[:, None] + np.arange(nelem, dtype=np.uint64)[None, :] * np.uint64(0xC2B2AE35)) & _M32)
+    thr = np.uint64(int(np.floor(np.float64(np.float32(rate)) * 4294967296.0)))
+    return np.where(u >= thr, dtype(1) / (dtype(1) - dtype(np.float32(rate))), dtype(0)).astype(dtype)
+
+
+def loss_and_grads_deployed(x, y, weights: Weights, dtype=np.float64, dropout: Optional[dict] = None):
+    """CNN.ipynb cell 6 net: returns (mean loss, per-sample losses, [(dkernel, dbias)] of the MEAN loss, probs).
+    dropout = {'rate', 'seed', 'step', 'frames'}: the optional Dropout behind the conv activations (see above)."""
     (ck, cb), (wd, bd) = weights
     x, y = _as(x, dtype), _as(y, dtype)
     F = ck.shape[-1]
@@ -85,6 +122,10 @@ def loss_and_grads_deployed(x, y, weights: Weights, dtype=np.float64):
     pre = x0 * k[0] + x1 * k[1] + b
     a = np.maximum(pre, 0)
     flat = a.reshape(n, 258 * F)
+    keep = None
+    if dropout is not None and dropout["rate"] > 0:
+        keep = dropout_scale(dropout["rate"], dropout["seed"], dropout["step"], dropout["frames"], 258 * F, 0, dtype)
+        flat = flat * keep
     z = flat @ wd + bd
     d = np.maximum(z, 0)
     p = _softmax(d)
@@ -92,14 +133,18 @@ def loss_and_grads_deployed(x, y, weights: Weights, dtype=np.float64):
     gz = _softmax_backward(p, gp) * (z > 0) / dtype(n)
     dwd = flat.T @ gz
     dbd = gz.sum(axis=0)
-    ga = (gz @ wd.T).reshape(n, 2, 129, F) * (pre > 0)
+    gflat = gz @ wd.T
+    if keep is not None:
+        gflat = gflat * keep
+    ga = gflat.reshape(n, 2, 129, F) * (pre > 0)
     dk = np.stack([(ga * x0).sum(axis=(0, 1, 2)), (ga * x1).sum(axis=(0, 1, 2))]).reshape(ck.shape)
     db = ga.sum(axis=(0, 1, 2))
     return float(li.mean(dtype=np.float64)), li, [(dk, db), (dwd, dbd)], p
 
 
-def loss_and_grads_cnnpy(x, y, weights: Weights, dtype=np.float64):
-    """cnn.py:104-112 as TensorFlow builds it: (H, W, C) = (1, 2, 128), pad W by 1, Conv2D(F,(1,2)) -> (1,3,F)."""
+def loss_and_grads_cnnpy(x, y, weights: Weights, dtype=np.float64, dropout: Optional[dict] = None):
+    """cnn.py:104-112 as TensorFlow builds it: (H, W, C) = (1, 2, 128), pad W by 1, Conv2D(F,(1,2)) -> (1,3,F).
+    dropout: optional Dropout behind the conv activations (site 0) and behind Dense(D, relu) (site 1)."""
     (ck, cb), (w1, b1), (w2, b2) = weights
     x, y = _as(x, dtype), _as(y, dtype)
     F = ck.shape[-1]
@@ -111,16 +156,29 @@ def loss_and_grads_cnnpy(x, y, weights: Weights, dtype=np.float64):
     pre = np.stack([xp[:, w] @ k[0] + xp[:, w + 1] @ k[1] for w in range(3)], axis=1) + cb      # (n,3,F)
     a = np.maximum(pre, 0)
     flat = a.reshape(n, 3 * F)
+    keep0 = keep1 = None
+    if dropout is not None and dropout["rate"] > 0:
+        keep0 = dropout_scale(dropout["rate"], dropout["seed"], dropout["step"], dropout["frames"], 3 * F, 0, dtype)
+        keep1 = dropout_scale(dropout["rate"], dropout["seed"], dropout["step"], dropout["frames"], w1.shape[1], 1, dtype)
+        flat = flat * keep0
     z1 = flat @ w1 + b1
     h = np.maximum(z1, 0)
+    if keep1 is not None:
+        h = h * keep1
     lg = h @ w2 + b2
     p = _softmax(lg)
     li, gp = crossentropy_on_probs(p, y)
     glg = _softmax_backward(p, gp) / dtype(n)
     dw2, db2 = h.T @ glg, glg.sum(axis=0)
-    gz1 = (glg @ w2.T) * (z1 > 0)
+    gh = glg @ w2.T
+    if keep1 is not None:
+        gh = gh * keep1
+    gz1 = gh * (z1 > 0)
     dw1, db1 = flat.T @ gz1, gz1.sum(axis=0)
-    ga = (gz1 @ w1.T).reshape(n, 3, F) * (pre > 0)
+    gflat = gz1 @ w1.T
+    if keep0 is not None:
+        gflat = gflat * keep0
+    ga = gflat.reshape(n, 3, F) * (pre > 0)
     dk = np.zeros((2, 128, F), dtype)
     for w in range(3):
         dk[0] += xp[:, w].T @ ga[:, w]
@@ -128,11 +186,11 @@ def loss_and_grads_cnnpy(x, y, weights: Weights, dtype=np.float64):
     return float(li.mean(dtype=np.float64)), li, [(dk.reshape(ck.shape), ga.sum(axis=(0, 1))), (dw1, db1), (dw2, db2)], p
 
 
-def loss_and_grads(kind: str, x, y, weights: Weights, dtype=np.float64):
+def loss_and_grads(kind: str, x, y, weights: Weights, dtype=np.float64, dropout: Optional[dict] = None):
     if kind == "deployed":
-        return loss_and_grads_deployed(x, y, weights, dtype)
+        return loss_and_grads_deployed(x, y, weights, dtype, dropout)
     if kind == "cnnpy":
-        return loss_and_grads_cnnpy(x, y, weights, dtype)
+        return loss_and_grads_cnnpy(x, y, weights, dtype, dropout)
     raise ValueError(f"the reference trains the deployed and cnn.py nets only, not {kind!r}")
 
 
@@ -171,9 +229,12 @@ def flatten_weights(weights: Weights) -> List[np.ndarray]:
     return [t for pair in weights for t in pair]
 
 
-def train_step(kind: str, x, y, weights: Weights, opt: KerasAdam, dtype=np.float32) -> float:
-    """train_on_batch: gradients of the batch's mean loss in `dtype`, then the Adam update of the f32 weights IN PLACE."""
-    loss, _li, grads, _p = loss_and_grads(kind, x, y, weights, dtype)
+def train_step(kind: str, x, y, weights: Weights, opt: KerasAdam, dtype=np.float32, dropout: Optional[dict] = None) -> float:
+    """train_on_batch: gradients of the batch's mean loss in `dtype`, then the Adam update of the f32 weights IN PLACE.
+    dropout = {'rate', 'seed', 'frames'}: the step is the optimizer's iteration count."""
+    if dropout is not None:
+        dropout = dict(dropout, step=opt.iterations)
+    loss, _li, grads, _p = loss_and_grads(kind, x, y, weights, dtype, dropout)
     opt.apply(flatten_weights(weights), flatten_weights(grads))
     return loss
 

@@ -46,6 +46,7 @@ def test_trainer_entry_points_validate_their_arguments_without_gpu():
     assert L.mdc_trainer_evaluate(None, None, None, None, 0, 1, None) == -22
     assert L.mdc_trainer_num_layers(None) == -22
     assert L.mdc_trainer_set_adam(None, 1e-3, 0.9, 0.999, 1e-7) == -22
+    assert L.mdc_trainer_set_dropout(None, 0.5, 0) == -22
     assert L.mdc_trainer_read(None, 0, None, None, None, None, None, None) == -22
     L.mdc_trainer_destroy(None)
 

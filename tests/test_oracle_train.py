@@ -164,3 +164,57 @@ def test_fit_callbacks_early_stopping_and_best_checkpoint():
     assert abs(T.evaluate("deployed", xv, yv, h["best_weights"]) - v[be]) < 1e-7
     # 128 frames in batches of 50: 50 + 50 + 28 -- the short batch is trained on (3 Adam steps per epoch)
     assert h["opt"].iterations == 3 * len(v)
+
+
+@pytest.mark.parametrize("rate", [0.1, 0.5, 0.6])
+def test_dropout_generator_statistics(rate):
+    """The stated counter-based generator behind the OPTIONAL Dropout (include/mdc.h, mdc_trainer_set_dropout): keep fraction
+    1 - rate within 4 sigma, scale 1 / (1 - rate), a fresh mask at every step and for every site, no correlation between
+    neighbouring elements or frames, and a frame's mask independent of which other frames are in the batch."""
+    n, e = 4000, 774
+    m = T.dropout_scale(rate, 2016, 0, np.arange(n), e, 0)
+    keep = m > 0
+    sigma = np.sqrt(rate * (1 - rate) / (n * e))
+    assert abs(keep.mean() - (1 - rate)) < 4 * sigma
+    assert np.allclose(m[keep], 1.0 / (1.0 - np.float64(np.float32(rate))))
+    for other in (T.dropout_scale(rate, 2016, 1, np.arange(n), e, 0) > 0,       # next step
+                  T.dropout_scale(rate, 2016, 0, np.arange(n), e, 1) > 0,       # other site
+                  T.dropout_scale(rate, 2017, 0, np.arange(n), e, 0) > 0):      # other seed
+        agree = (keep == other).mean()
+        assert abs(agree - (rate ** 2 + (1 - rate) ** 2)) < 5e-3                # what two independent masks agree on
+    assert abs(np.corrcoef(keep[:, :-1].ravel(), keep[:, 1:].ravel())[0, 1]) < 5e-3
+    assert abs(np.corrcoef(keep[:-1].ravel(), keep[1:].ravel())[0, 1]) < 5e-3
+    sub = T.dropout_scale(rate, 2016, 0, np.array([17, 3999, 5]), e, 0)
+    assert np.array_equal(sub, m[[17, 3999, 5]])
+
+
+@pytest.mark.parametrize("kind,F", [("deployed", 3), ("cnnpy", 10)])
+def test_dropout_gradients_match_torch_autograd(kind, F):
+    topo, w, x, y = _case(kind, F, seed=13)
+    drop = dict(rate=0.5, seed=7, step=3, frames=np.arange(len(x)) + 100)
+    loss, li, grads, p = T.loss_and_grads(kind, x, y, w, np.float64, dropout=drop)
+    tw = [(torch.tensor(k, dtype=torch.float64, requires_grad=True), torch.tensor(b, dtype=torch.float64, requires_grad=True)) for k, b in w]
+    n = len(x)
+    tx, ty = torch.tensor(x), torch.tensor(y)
+    if kind == "deployed":
+        (ck, cb), (wd, bd) = tw
+        a = torch.relu(Fnn.conv2d(Fnn.pad(tx.reshape(n, 1, 2, 128), (1, 1)), ck.permute(3, 2, 0, 1), cb))
+        flat = a.permute(0, 2, 3, 1).reshape(n, 258 * F) * torch.tensor(T.dropout_scale(0.5, 7, 3, drop["frames"], 258 * F, 0))
+        out = torch.relu(flat @ wd + bd)
+    else:
+        (ck, cb), (w1, b1), (w2, b2) = tw
+        a = torch.relu(Fnn.conv2d(Fnn.pad(tx.reshape(n, 1, 2, 128).permute(0, 3, 1, 2), (1, 1)), ck.permute(3, 2, 0, 1), cb))
+        flat = a.permute(0, 2, 3, 1).reshape(n, 3 * F) * torch.tensor(T.dropout_scale(0.5, 7, 3, drop["frames"], 3 * F, 0))
+        h = torch.relu(flat @ w1 + b1) * torch.tensor(T.dropout_scale(0.5, 7, 3, drop["frames"], w1.shape[1], 1))
+        out = h @ w2 + b2
+    pr = torch.softmax(out, dim=-1)
+    q = torch.clamp(pr / pr.sum(dim=-1, keepdim=True), 1e-7, 1 - 1e-7)
+    tl = (-(ty * torch.log(q)).sum(dim=-1)).mean()
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-12
+    loss0, *_ = T.loss_and_grads(kind, x, y, w, np.float64)
+    assert abs(loss - loss0) > 1e-6                                             # the mask acts
+    for (dk, db), (tk, tb) in zip(grads, tw):
+        for g, t in ((dk, tk), (db, tb)):
+            ref = t.grad.numpy()
+            assert np.abs(g - ref).max() <= 1e-10 * np.abs(ref).max()

@@ -356,3 +356,84 @@ def test_gradient_is_additive_over_the_batch_at_full_size(kind, topo):
         mix_k = (ka.astype(np.float64) * cut + kb.astype(np.float64) * (n - cut)) / n
         mix_b = (ba.astype(np.float64) * cut + bb.astype(np.float64) * (n - cut)) / n
         assert _rel(k, mix_k) <= 2e-5 and _rel(b, mix_b) <= 2e-5, (_rel(k, mix_k), _rel(b, mix_b))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The OPTIONAL Dropout (mdc_trainer_set_dropout): off in every test above -- the reference's nets contain no Dropout layer.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,topo", CASES[:4], ids=IDS[:4])
+def test_dropout_masks_are_the_stated_generators(kind, topo):
+    """With Dropout on, the gradients of a batch addressed through a shuffle equal the oracle's with the masks of the STATED
+    generator (seed, step = Adam's iteration count, the frames' data-set indices): the kernels draw exactly those bits.  The
+    mask acts (loss differs from the dropout-free one), is the same until a step is applied, and evaluation never sees it."""
+    import torch
+    n = 700
+    w = synthetic_weights(topo, seed=3, bias_scale=0.05)
+    x, y = _data(topo, n, seed=17)
+    perm = np.random.default_rng(5).permutation(n).astype(np.int32)
+    sel = perm[100:100 + 513]
+    tr = Trainer(topo, w, device=0, dropout=0.5, dropout_seed=2016)
+    xd, yd, od = tr._frames(x), tr._targets(y, n), torch.from_numpy(perm).cuda()
+
+    def grads_now():
+        tr.read(reset=True)
+        tr.train_batch(xd, yd, od, 100, 513, apply=False)
+        r = tr.read(reset=True)
+        return r["train_loss_sum"] / 513, tr.gradients()
+
+    loss, g = grads_now()
+    ref_loss, _li, ref_g, _p = T.loss_and_grads(kind, x[sel], y[sel], w, np.float64, dropout=dict(rate=0.5, seed=2016, step=0, frames=sel))
+    _pl, _pli, plain_g, _pp = T.loss_and_grads(kind, x[sel], y[sel], w, np.float64)
+    assert abs(loss - ref_loss) <= 1e-5 * ref_loss
+    assert _rel(ref_g[-1][0], plain_g[-1][0]) > 0.1             # the mask acts: these are not the dropout-free gradients
+    for (gk, gb), (rk, rb) in zip(g, ref_g):
+        assert _rel(gk, rk) <= 1e-5 and _rel(gb, rb) <= 2e-5, (_rel(gk, rk), _rel(gb, rb))
+    loss2, g2 = grads_now()                                     # nothing applied: the same step, the same masks, the same bits
+    assert loss2 == loss and all(np.array_equal(a, c) and np.array_equal(b, d) for (a, b), (c, d) in zip(g, g2))
+    ev = tr.evaluate(x, y)                                      # inference: no mask
+    assert abs(ev - T.evaluate(kind, x, y, w, np.float64)) <= 1e-5 * ev
+
+
+@pytest.mark.parametrize("kind,topo", [CASES[0], CASES[2]], ids=[IDS[0], IDS[2]])
+def test_dropout_trajectory_draws_a_new_mask_every_step_also_under_graph_replay(kind, topo):
+    import torch
+    w = synthetic_weights(topo, seed=6, bias_scale=0.02)
+    x, y = _data(topo, 1024, seed=23)
+    frames = np.arange(1024)
+    wo = [(k.copy(), b.copy()) for k, b in w]
+    opt = T.KerasAdam([t.shape for t in T.flatten_weights(wo)])
+    for _ in range(6):
+        T.train_step(kind, x, y, wo, opt, np.float64, dropout=dict(rate=0.3, seed=9, frames=frames))
+    eager, graph = (Trainer(topo, w, device=0, dropout=0.3, dropout_seed=9) for _ in range(2))
+    xd, yd = eager._frames(x), eager._targets(y, 1024)
+    for _ in range(6):
+        eager.train_batch(xd, yd)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.read()
+        with torch.cuda.graph(g, stream=side):
+            graph.train_batch(xd, yd)
+            graph.train_batch(xd, yd)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert eager.read()["iterations"] == graph.read()["iterations"] == 6
+    for (k, b), (k2, b2), (rk, rb) in zip(eager.get_weights(), graph.get_weights(), wo):
+        assert np.array_equal(k, k2) and np.array_equal(b, b2)                  # the step count lives on the device
+        assert np.abs(k - rk).max() <= 1e-4 and np.abs(b - rb).max() <= 1e-4    # ... and keys the oracle's masks
+
+
+def test_dropout_through_the_mirror_and_its_refusals():
+    topo = Topology.deployed(3)
+    x, lab = _leveled(2000, seed=3)
+    m = VTCNN2.synthetic(topo, seed=4, device=0)
+    m.compile(lr=0.01, dropout=0.5, dropout_seed=1)
+    h = m.fit(x[:1500], to_onehot(lab[:1500], 3), batch_size=512, epochs=6, validation_data=(x[1500:], to_onehot(lab[1500:], 3)), seed=0)
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    assert m.trainer().dropout == 0.5
+    L = _cabi.lib()
+    assert L.mdc_trainer_set_dropout(m.trainer()._h, 1.0, 0) == -22 and L.mdc_trainer_set_dropout(m.trainer()._h, -0.1, 0) == -22
+    assert L.mdc_trainer_set_dropout(None, 0.5, 0) == -22
