@@ -8,11 +8,15 @@ old-style groups (v1 B-tree -> SNOD -> local heap), v1 object headers with
 continuation blocks, contiguous f32 datasets, v1 attributes holding fixed
 strings, arrays of fixed strings, or variable-length strings in a global heap.
 
-Nothing from the file is executed; it is parsed as bytes only.
+Nothing from the file is executed; it is parsed as bytes only.  A file is untrusted input: whatever is wrong with it --
+truncation, offsets into nowhere, cyclic or shared group links, sizes that do not fit the file -- comes out as
+``H5FormatError`` (a ``ValueError``) in time and memory bounded by the file's own size, never as a struct / index /
+unicode / recursion error, a hang, or an allocation the file's length does not justify (``tests/test_h5_fuzz.py``).
 """
 from __future__ import annotations
 
 import json
+import math
 import struct
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -21,6 +25,11 @@ import numpy as np
 
 _SIG = b"\x89HDF\r\n\x1a\n"
 _UNDEF = 0xFFFFFFFFFFFFFFFF
+_MAX_UNALLOCATED = 1 << 26      # elements of a dataset with no storage (reads as zeros) this reader will materialise
+_MAX_MEMBERS = 1 << 16          # members of one group
+# what a parser of hostile bytes can trip over before its own checks speak; all of it means "this is not a file we read"
+_PARSE_ERRORS = (struct.error, IndexError, KeyError, UnicodeDecodeError, OverflowError, TypeError, ValueError, RecursionError,
+                 MemoryError)
 
 
 class H5FormatError(ValueError):
@@ -76,9 +85,15 @@ class H5File:
             raise H5FormatError(f"superblock version {b[8]} unsupported (need 0)")
         if b[13] != 8 or b[14] != 8:
             raise H5FormatError("only 8-byte offsets/lengths supported")
-        # superblock v0: root group symbol-table entry starts at byte 56
-        root_hdr = struct.unpack_from("<Q", b, 64)[0]
-        self.root = self._read_object("/", root_hdr)
+        self._seen: set = set()      # object headers and B-tree nodes already walked: a second visit is a cycle or a hard link
+        try:
+            # superblock v0: root group symbol-table entry starts at byte 56
+            root_hdr = struct.unpack_from("<Q", b, 64)[0]
+            self.root = self._read_object("/", root_hdr)
+        except H5FormatError:
+            raise
+        except _PARSE_ERRORS as e:
+            raise H5FormatError(f"{path}: corrupt or truncated HDF5 structure ({type(e).__name__}: {e})") from e
 
     # -- low level ---------------------------------------------------------
     def _u(self, fmt: str, off: int):
@@ -130,7 +145,7 @@ class H5File:
             doff = off + 4
         else:
             raise H5FormatError(f"dataspace version {ver}")
-        return tuple(self._u("Q", doff + 8 * i)[0] for i in range(rank))
+        return tuple(int(self._u("Q", doff + 8 * i)[0]) for i in range(rank))
 
     def _global_heap_object(self, coll_addr: int, index: int) -> bytes:
         b = self.buf
@@ -159,7 +174,9 @@ class H5File:
         p += pad(tsize)
         shape = self._parse_dataspace(p) if ssize else ()
         p += pad(ssize)
-        count = int(np.prod(shape)) if shape else 1
+        count = math.prod(shape) if shape else 1
+        if count * max(dt.size, 1) > len(self.buf):
+            raise H5FormatError(f"attribute {name!r}: {count} elements do not fit the file")
         if dt.cls == 9:
             if not dt.vlen_string:
                 raise H5FormatError("only vlen strings supported")
@@ -189,8 +206,13 @@ class H5File:
             return b[s:b.index(b"\0", s)].decode("utf-8")
 
         def walk(node: int) -> None:
+            if ("n", node) in self._seen:
+                raise H5FormatError("a group B-tree node is linked twice (cycle)")
+            self._seen.add(("n", node))
             if b[node:node + 4] == b"SNOD":
                 nsym = self._u("H", node + 6)[0]
+                if len(out) + nsym > _MAX_MEMBERS:
+                    raise H5FormatError("too many members in one group")
                 for i in range(nsym):
                     e = node + 8 + 40 * i
                     noff, hdr = self._u("QQ", e)
@@ -209,6 +231,9 @@ class H5File:
         return out
 
     def _read_object(self, name: str, addr: int) -> H5Object:
+        if ("o", addr) in self._seen:
+            raise H5FormatError(f"object {name!r} is linked twice (cycle or hard link: not in a Keras save)")
+        self._seen.add(("o", addr))
         obj = H5Object(name=name, addr=addr)
         symtab = None
         for mtype, _flags, off, size in self._messages(addr):
@@ -252,12 +277,19 @@ class H5File:
         ds = self.get(path)
         if not ds.is_dataset:
             raise KeyError(f"{path!r} is not a dataset")
-        dt = ds.dtype.numpy()
-        count = int(np.prod(ds.shape)) if ds.shape else 1
+        try:
+            dt = ds.dtype.numpy()
+        except TypeError as e:
+            raise H5FormatError(f"{path!r}: element size {ds.dtype.size} is no numpy type") from e
+        count = math.prod(ds.shape) if ds.shape else 1
         if ds.compact is not None:
+            if count * dt.itemsize > len(ds.compact):
+                raise H5FormatError(f"{path!r}: compact data shorter than its shape")
             arr = np.frombuffer(ds.compact, dtype=dt, count=count)
         else:
             if ds.data_addr in (None, _UNDEF):
+                if count > _MAX_UNALLOCATED:
+                    raise H5FormatError(f"{path!r}: {count} unallocated elements")
                 return np.zeros(ds.shape, dtype=dt.newbyteorder("="))
             if ds.data_addr + count * dt.itemsize > len(self.buf):
                 raise H5FormatError(f"{path!r}: data runs past end of file")
@@ -298,21 +330,29 @@ def load_keras_h5(path: str) -> KerasCheckpoint:
     cfg_raw = root.attrs.get("model_config")
     if cfg_raw is None:
         raise H5FormatError("no model_config attribute: not a Keras full-model save")
-    mw = f.get("model_weights") if "model_weights" in root.children else root
-    layer_names = [str(s) for s in mw.attrs.get("layer_names", [])]
-    weights: Dict[str, List[Tuple[str, np.ndarray]]] = {}
-    for lname in layer_names:
-        grp = mw.children[lname]
-        wnames = grp.attrs.get("weight_names", [])
-        if isinstance(wnames, str):
-            wnames = [wnames]
-        base = "model_weights/" if mw is not root else ""
-        weights[lname] = [(str(w), f.read(f"{base}{lname}/{w}")) for w in wnames]
+    try:
+        mw = f.get("model_weights") if "model_weights" in root.children else root
+        layer_names = [str(s) for s in np.atleast_1d(mw.attrs.get("layer_names", [])).tolist()]
+        weights: Dict[str, List[Tuple[str, np.ndarray]]] = {}
+        for lname in layer_names:
+            grp = mw.children[lname]
+            wnames = grp.attrs.get("weight_names", [])
+            if isinstance(wnames, str):
+                wnames = [wnames]
+            base = "model_weights/" if mw is not root else ""
+            weights[lname] = [(str(w), f.read(f"{base}{lname}/{w}")) for w in wnames]
+        model_config = json.loads(cfg_raw)
+        if not isinstance(model_config, dict):
+            raise H5FormatError("model_config is not a JSON object")
+    except H5FormatError:
+        raise
+    except _PARSE_ERRORS as e:
+        raise H5FormatError(f"{path}: not a consistent Keras save ({type(e).__name__}: {e})") from e
     return KerasCheckpoint(
         path=path,
         keras_version=str(root.attrs.get("keras_version", "")),
         backend=str(root.attrs.get("backend", "")),
-        model_config=json.loads(cfg_raw),
+        model_config=model_config,
         layer_names=layer_names,
         weights=weights,
     )

@@ -39,7 +39,15 @@ class Topology:
 
     @staticmethod
     def from_keras_config(cfg: dict) -> "Topology":
-        """Recognise a Keras ``model_config`` (the JSON attribute inside a .h5)."""
+        """Recognise a Keras ``model_config`` (the JSON attribute inside a .h5).  Anything else -- another model, or JSON that is
+        not a Sequential config at all -- is a ValueError."""
+        try:
+            return Topology._from_keras_config(cfg)
+        except (KeyError, TypeError, AttributeError, IndexError) as e:
+            raise ValueError(f"not a Keras Sequential model_config ({type(e).__name__}: {e})") from e
+
+    @staticmethod
+    def _from_keras_config(cfg: dict) -> "Topology":
         layers = [(l["class_name"], l["config"]) for l in cfg["config"]["layers"] if l["class_name"] != "InputLayer"]
         names = [n for n, _ in layers]
         convs = [c for n, c in layers if n == "Conv2D"]

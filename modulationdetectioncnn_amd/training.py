@@ -180,8 +180,22 @@ class Trainer:
         return y
 
     # ------------------------------------------------------------------ steps
+    def _resident(self, x, y, order=None) -> None:
+        """The raw pointers below are dereferenced by the kernels: refuse anything that is not a contiguous tensor of the expected
+        type in THIS device's memory (a host tensor's data_ptr() would be a GPU fault, not an error).  The VALUES of `order` are the
+        caller's to keep inside [0, len(x)) -- fit() checks the permutations it is given on the host."""
+        torch = _torch()
+        want = (("frames", x, torch.float32, (2, 128)), ("targets", y, torch.float32, (self.topology.classes,)))
+        for name, t, dt, tail in want + ((("order", order, torch.int32, ()),) if order is not None else ()):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device.index != self.device_index or t.dtype != dt \
+                    or not t.is_contiguous() or tuple(t.shape[1:]) != tail:
+                raise ValueError(f"{name}: expected a contiguous {dt} tensor (n,{','.join(map(str, tail))}) on cuda:{self.device_index}")
+        if y.shape[0] != x.shape[0]:
+            raise ValueError(f"{x.shape[0]} frames but {y.shape[0]} target rows")
+
     def train_batch(self, x, y, order=None, first: int = 0, count: Optional[int] = None, apply: bool = True) -> None:
         """model.train_on_batch on frames order[first:first+count] of the device-resident set (x, y); enqueue only."""
+        self._resident(x, y, order)
         n = x.shape[0] if order is None else order.shape[0]
         count = n - first if count is None else int(count)
         if first < 0 or count < 0 or first + count > n:
@@ -190,6 +204,7 @@ class Trainer:
                                                 first, count, int(apply), self._stream()))
 
     def evaluate_enqueue(self, x, y) -> None:
+        self._resident(x, y)
         self._check(self._lib().mdc_trainer_evaluate(self._h, x.data_ptr(), y.data_ptr(), None, 0, x.shape[0], self._stream()))
 
     def read(self, reset: bool = True) -> Dict:
@@ -251,8 +266,8 @@ class Trainer:
                 order_h = np.asarray(permutations(ep), dtype=np.int32)
             else:
                 order_h = (rng.permutation(n) if shuffle else np.arange(n)).astype(np.int32)
-            if order_h.shape != (n,):
-                raise ValueError("a permutation needs one index per frame")
+            if order_h.shape != (n,) or (n and (int(order_h.min()) < 0 or int(order_h.max()) >= n)):
+                raise ValueError(f"a permutation needs one index in [0, {n}) per frame")
             order = torch.from_numpy(order_h).to(dev)
             for s in range(0, n, batch_size):
                 self.train_batch(x, y, order, s, min(batch_size, n - s), apply=True)

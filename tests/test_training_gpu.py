@@ -298,6 +298,18 @@ def test_refusals():
         tr.evaluate(x[:, :1], y)
     with pytest.raises(ValueError):
         tr.train_batch(tr._frames(x), tr._targets(y, 8), None, 4, 8)
+    import torch
+    xd, yd = tr._frames(x), tr._targets(y, 8)
+    for bad in ((torch.from_numpy(x), yd, None),                              # host memory: its data_ptr() must never reach a kernel
+                (xd.double(), yd, None), (xd[:, :, ::2], yd, None), (xd, yd[:4], None),
+                (xd, yd, torch.arange(8, device="cuda")),                      # int64 indices
+                (xd, yd, torch.arange(8, dtype=torch.int32))):                # indices in host memory
+        with pytest.raises(ValueError):
+            tr.train_batch(*bad)
+    with pytest.raises(ValueError):
+        tr.evaluate_enqueue(torch.from_numpy(x), yd)
+    with pytest.raises(ValueError):                                           # a "permutation" that points outside the data set
+        tr.fit(x, y, batch_size=4, epochs=1, permutations=lambda ep: np.arange(1, 9))
     L = _cabi.lib()
     import ctypes as C
     h = C.c_void_p()
