@@ -9,7 +9,8 @@
                                                                        checkpoint=filepath, patience=5)   (training.py)
     model.predict(X, batch_size=1024) cnn.py:198       m.predict(X, batch_size=1024)
     int(np.argmax(Y_hat[i,:]))        cnn.py:209       m.predict_classes(X)
-    Model(inputs, layers[i].output)   CNN.ipynb c.17   m.predict(X, tap='conv'|'flat'|'dense')
+    Model(inputs, layers[i].output)   CNN.ipynb c.17   m.predict(X, tap='conv'|'flat'|'dense'), or the cell's own spelling:
+                                                       Model(inputs=m.inputs, outputs=m.layers[4].output).predict(X)
 
 All arithmetic runs in libmdc.so (hand-written gfx950 HIP) through the C ABI in
 include/mdc.h; PyTorch-ROCm only supplies device memory and the HIP stream.  numpy in ->
@@ -364,6 +365,18 @@ class VTCNN2:
         captured from this model's forwards has been destroyed: a replay after this writes through a stale address."""
         self._ws_captured = []
 
+    # ------------------------------------------------------------------ model.layers / model.inputs (CNN.ipynb cells 15, 17)
+    @property
+    def layers(self) -> List["Layer"]:
+        """The Sequential's layers in Keras' order (`print(model.layers[2])`, `model.layers[4].output`: CNN.ipynb cells 15, 17)."""
+        rows = self.topology.keras_layers()
+        names = self.topology.keras_layer_names()
+        return [Layer(self, i, cls, name, shape, params) for i, ((cls, shape, params), (_role, name)) in enumerate(zip(rows, names))]
+
+    @property
+    def inputs(self) -> "ModelInputs":
+        return ModelInputs(self)
+
     # ------------------------------------------------------------------ inference
     def tap_shape(self, tap: str) -> Tuple[int, ...]:
         t = self.topology
@@ -693,3 +706,100 @@ class VTCNN2:
             self._check(L.mdc_profile_read(h, i, C.byref(ms), C.byref(cnt)))
             out[L.mdc_profile_name(h, i).decode()] = (ms.value, cnt.value)
         return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CNN.ipynb cell 17 spelled as the notebook spells it:
+#     model2 = Model(inputs = model.inputs, outputs = model.layers[4].output)   # dense + ReLU, no softmax
+#     model2.compile(loss='categorical_crossentropy', optimizer='adam'); model2.predict(np.array([X_test[i],]))
+# A sub-model is a VIEW of its parent: the same device weights, one forward with the layer's tap (MDC_TAP_*), the result in
+# the shape Keras gives that layer's output.  Layers whose output the kernels never materialise (the input reshapes and
+# paddings, VT-CNN2's first convolution -- conv1 feeds conv2 from registers) have no tap and say so.
+# ----------------------------------------------------------------------------------------------------------------------
+class ModelInputs:
+    def __init__(self, model: VTCNN2):
+        self.model = model
+
+    def __repr__(self):
+        return "[<input (None, 2, 128) float32>]"
+
+
+class LayerOutput:
+    def __init__(self, layer: "Layer"):
+        self.layer = layer
+
+    @property
+    def shape(self):
+        return self.layer.output_shape
+
+    def __repr__(self):
+        return f"<output of {self.layer!r} {self.layer.output_shape}>"
+
+
+class Layer:
+    """One entry of `model.layers`: what the reference prints, reads weights from and taps."""
+
+    def __init__(self, model: VTCNN2, index: int, class_name: str, name: str, shape: Tuple[int, ...], params: int):
+        self.model, self.index, self.class_name, self.name = model, index, class_name, name
+        self.output_shape = (None,) + tuple(shape)
+        self._params = params
+
+    def __repr__(self):
+        return f"<{self.class_name} {self.name}>"
+
+    def count_params(self) -> int:
+        return self._params
+
+    def get_weights(self) -> List[np.ndarray]:
+        """[kernel, bias] of a Conv2D / Dense in the layout Keras holds them, [] for the others (`layer.get_weights()`)."""
+        if self._params == 0:
+            return []
+        rows = self.model.topology.keras_layers()
+        k = sum(1 for _c, _s, p in rows[:self.index] if p)
+        kernel, bias = self.model.get_weights()[k]
+        return [kernel, bias]
+
+    @property
+    def output(self) -> LayerOutput:
+        return LayerOutput(self)
+
+    @property
+    def tap(self) -> Optional[str]:
+        """The MDC_TAP_* name that yields this layer's output; None = the model's own output (softmax rows)."""
+        kind, i = self.model.topology.kind, self.index
+        table = {"deployed": {2: "conv", 3: "flat", 4: "dense", 5: None, 6: None},
+                 "cnnpy": {2: "conv", 3: "flat", 4: "hidden", 5: "dense", 6: None, 7: None},
+                 # Dropout is the identity at inference: its output is its input's
+                 "vtcnn2": {5: "conv", 6: "conv", 7: "flat", 8: "hidden", 9: "hidden", 10: "dense", 11: None, 12: None}}[kind]
+        if i not in table:
+            raise ValueError(f"{self!r}: this layer's output is never materialised by the kernels (input reshapes / paddings; "
+                             "VT-CNN2's conv1 feeds conv2 from registers) -- no tap")
+        return table[i]
+
+
+class SubModel:
+    """`Model(inputs=model.inputs, outputs=model.layers[i].output)`: predict() = one forward of the parent with that tap."""
+
+    def __init__(self, parent: VTCNN2, layer: Layer):
+        self.parent, self.layer, self._tap = parent, layer, layer.tap      # (raises here for a layer without a tap)
+
+    def compile(self, *_a, **_k) -> None:
+        """The notebook compiles its sub-models before predicting; nothing to prepare here."""
+
+    @property
+    def output_shape(self):
+        return self.layer.output_shape
+
+    def predict(self, X, batch_size: Optional[int] = None):
+        out = self.parent.predict(X, batch_size=batch_size, tap=self._tap)
+        return out.reshape((out.shape[0],) + tuple(self.layer.output_shape[1:]))
+
+
+def Model(inputs=None, outputs=None) -> SubModel:
+    """keras.models.Model(inputs=model.inputs, outputs=model.layers[i].output) for a layer of a VTCNN2 (CNN.ipynb cell 17)."""
+    if not isinstance(outputs, LayerOutput):
+        raise TypeError("outputs must be `model.layers[i].output` of a VTCNN2")
+    parent = outputs.layer.model
+    if inputs is not None and not (isinstance(inputs, ModelInputs) and inputs.model is parent):
+        raise ValueError("inputs must be the same model's `model.inputs`")
+    return SubModel(parent, outputs.layer)
