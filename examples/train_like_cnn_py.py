@@ -4,7 +4,7 @@
     X_train / X_test / Y_train / Y_test from the dataset dict                 cnn.py:42-82   -> formats/rml2016.py (or synthetic cells)
     model = Sequential([... Conv2D ... Dense ...]); model.compile(            cnn.py:104-113 -> VTCNN2.synthetic(topology) (glorot_uniform /
         loss='categorical_crossentropy', optimizer='adam')                                      he_normal / zero biases); model.compile(...)
-    history = model.fit(X_train, Y_train, batch_size=1024, epochs=100,        cnn.py:135-146 -> model.fit(..., checkpoint=filepath, patience=5)
+    history = model.fit(X_train, Y_train, batch_size=1024, epochs=100,        cnn.py:135-146 -> the same call (callbacks module of this package)
         validation_data=(X_test, Y_test), callbacks=[ModelCheckpoint(filepath,
         monitor='val_loss', save_best_only=True), EarlyStopping(patience=5)])
     model.load_weights(filepath)                                              cnn.py:147     -> model.load_weights(filepath)  (Keras .h5)
@@ -26,7 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from modulationdetectioncnn_amd import VTCNN2, Topology      # noqa: E402
+from modulationdetectioncnn_amd import VTCNN2, Topology, callbacks      # noqa: E402   (`keras.callbacks` in the reference)
 from modulationdetectioncnn_amd.formats import rml2016        # noqa: E402
 from modulationdetectioncnn_amd.training import to_onehot     # noqa: E402
 
@@ -72,8 +72,12 @@ def main(argv=None):
     model = VTCNN2.synthetic(topo, seed=args.seed)                                                # cnn.py:104-112 (the initialisers)
     model.compile(loss="categorical_crossentropy", optimizer="adam", lr=args.lr)                  # cnn.py:113
     print(topo.summary())                                                                          # cnn.py:115
-    history = model.fit(X_train, Y_train, batch_size=args.batch_size, epochs=args.epochs, verbose=2,
-                        validation_data=(X_test, Y_test), checkpoint=args.filepath, patience=5, seed=args.seed)   # cnn.py:135-146
+    history = model.fit(X_train, Y_train, batch_size=args.batch_size, epochs=args.epochs, verbose=2,        # cnn.py:135-146
+                        validation_data=(X_test, Y_test),
+                        callbacks=[
+                            callbacks.ModelCheckpoint(args.filepath, monitor='val_loss', verbose=0, save_best_only=True, mode='auto'),
+                            callbacks.EarlyStopping(monitor='val_loss', patience=5, verbose=0, mode='auto')],
+                        seed=args.seed)                                  # (Keras' shuffle is unseeded; this one can be reproduced)
     model.load_weights(args.filepath)                                                              # cnn.py:147
     score = model.evaluate(X_test, Y_test, batch_size=args.batch_size)                             # cnn.py:153
     print(score)

@@ -4,5 +4,6 @@ libmdc.so (HIP).  The CPU oracle lives in /oracle and is never imported from her
 from .topology import Topology, synthetic_weights, synthetic_frames  # noqa: F401
 from .model import VTCNN2, Model  # noqa: F401
 from .frontend import frames_from_iq_u8  # noqa: F401
+from . import callbacks  # noqa: F401
 
-__all__ = ["Topology", "VTCNN2", "Model", "synthetic_weights", "synthetic_frames", "frames_from_iq_u8"]
+__all__ = ["Topology", "VTCNN2", "Model", "callbacks", "synthetic_weights", "synthetic_frames", "frames_from_iq_u8"]

@@ -220,7 +220,8 @@ class VTCNN2:
             checkpoint: Optional[str] = None, shuffle: bool = True, seed: Optional[int] = None, verbose: int = 0, **kw):
         """``model.fit(X_train, Y_train, batch_size, epochs, validation_data=(X_test, Y_test), callbacks=[ModelCheckpoint(
         checkpoint, monitor='val_loss', save_best_only=True), EarlyStopping(monitor='val_loss', patience=patience)])``
-        (cnn.py:135-146) for the deployed and cnn.py nets, f32, on the MI355X (csrc/train.hip).  As in Keras the model is
+        (cnn.py:135-146; ``callbacks=[...]`` with the two classes of ``modulationdetectioncnn_amd.callbacks`` is accepted
+        verbatim) for the deployed and cnn.py nets, f32, on the MI355X (csrc/train.hip).  As in Keras the model is
         left with the LAST epoch's weights; the best ones are in `checkpoint` (a Keras full-model .h5: ``load_weights`` it,
         as cnn.py:147 does) and in the returned history's ``best_weights``."""
         t = self.trainer()
@@ -470,8 +471,8 @@ class VTCNN2:
         probs, labels, tap_out = self.forward_device(x, tap=tap, batch_size=batch_size)
         return as_numpy, probs, labels, tap_out
 
-    def predict(self, X, batch_size: Optional[int] = None, tap: Optional[str] = None):
-        """``model.predict(X, batch_size)``: (n,C) float32 softmax rows; with ``tap`` the named
+    def predict(self, X, batch_size: Optional[int] = None, tap: Optional[str] = None, verbose: int = 0):
+        """``model.predict(X, batch_size)``: (n,C) float32 softmax rows (``verbose`` is accepted and says nothing); with ``tap`` the named
         intermediate layer of CNN.ipynb cell 17 instead.  Results do not depend on batch_size.  numpy in -> numpy out
         (through the streaming host-buffer driver); torch-ROCm tensor in -> tensor out on torch's current stream."""
         if tap is None and not isinstance(X, _torch().Tensor):
@@ -510,8 +511,8 @@ class VTCNN2:
             raise ValueError(f"{nbad} labels lie outside [0, {Cn})")
         return counts
 
-    def evaluate(self, X, Y, batch_size: Optional[int] = None) -> float:
-        """``score = model.evaluate(X_test, Y_test, batch_size=...)`` (cnn.py:153): the reference compiles its model with
+    def evaluate(self, X, Y, batch_size: Optional[int] = None, verbose: int = 0) -> float:
+        """``score = model.evaluate(X_test, Y_test, verbose=0, batch_size=...)`` (cnn.py:153): the reference compiles its model with
         loss='categorical_crossentropy' and no metric, so the score is the MEAN LOSS -- Keras' categorical cross-entropy
         on the softmax rows (row scaled to sum 1, clipped to [1e-7, 1 - 1e-7]).  Y: one-hot rows (n, C) as cnn.py:80-82
         builds them, or class indices (n,).  One forward, one reduction launch (mdc_crossentropy), one scalar read-back."""
@@ -790,7 +791,7 @@ class SubModel:
     def output_shape(self):
         return self.layer.output_shape
 
-    def predict(self, X, batch_size: Optional[int] = None):
+    def predict(self, X, batch_size: Optional[int] = None, verbose: int = 0):
         out = self.parent.predict(X, batch_size=batch_size, tap=self._tap)
         return out.reshape((out.shape[0],) + tuple(self.layer.output_shape[1:]))
 

@@ -236,14 +236,31 @@ class Trainer:
     # ------------------------------------------------------------------ the loop of cnn.py:135-146
     def fit(self, X, Y, batch_size: int = 1024, epochs: int = 100, validation_data=None, patience: Optional[int] = 5,
             checkpoint: Optional[str] = None, shuffle: bool = True, seed: Optional[int] = None, permutations=None,
-            verbose: int = 0, on_best=None) -> History:
+            verbose: int = 0, on_best=None, callbacks=None) -> History:
         """model.fit(X, Y, batch_size, epochs, validation_data=(Xv, Yv), callbacks=[ModelCheckpoint(checkpoint,
-        monitor='val_loss', save_best_only=True), EarlyStopping(monitor='val_loss', patience=patience)]).
+        monitor='val_loss', save_best_only=True), EarlyStopping(monitor='val_loss', patience=patience)]) -- pass the two
+        callbacks themselves (callbacks.py: cnn.py:143-144 verbatim) or their short forms `checkpoint=` / `patience=`.
         Every epoch trains on a fresh shuffle (numpy Generator(seed); Keras' own shuffle is unseeded) in batches of
         batch_size -- the last one short --, then computes val_loss; an improvement (strictly smaller) saves the
         checkpoint and resets the patience counter, `patience` epochs without one stop the run.  Without
-        validation_data both callbacks watch nothing (Keras warns and skips them): all epochs run, nothing is saved.
-        `permutations(epoch)` overrides the shuffle (tests).  on_best(epoch, val_loss, trainer): the checkpoint hook."""
+        validation_data a callback that monitors val_loss watches nothing (Keras warns and skips it): all epochs run,
+        nothing is saved.  `permutations(epoch)` overrides the shuffle (tests).  on_best(epoch, val_loss, trainer): called
+        whenever val_loss improves on every earlier epoch."""
+        from .callbacks import EarlyStopping, ModelCheckpoint
+        if callbacks is not None:
+            if checkpoint is not None:
+                raise ValueError("pass callbacks=[ModelCheckpoint(...)] or checkpoint=..., not both")
+            ckpts = [c for c in callbacks if isinstance(c, ModelCheckpoint)]
+            stops = [c for c in callbacks if isinstance(c, EarlyStopping)]
+            if len(ckpts) + len(stops) != len(callbacks) or len(ckpts) > 1 or len(stops) > 1:
+                raise ValueError("callbacks: at most one ModelCheckpoint and one EarlyStopping of this package's callbacks module")
+            ckpt, stop = (ckpts or [None])[0], (stops or [None])[0]
+        else:
+            ckpt = ModelCheckpoint(checkpoint, save_best_only=True) if checkpoint is not None else None
+            stop = EarlyStopping(patience=int(patience)) if patience is not None else None
+        for c in (ckpt, stop):
+            if c is not None:
+                c.reset()
         torch = _torch()
         x = self._frames(X)
         n = x.shape[0]
@@ -258,7 +275,7 @@ class Trainer:
             yv = self._targets(validation_data[1], xv.shape[0])
         rng = np.random.default_rng(seed)
         hist = History()
-        best, wait = np.inf, 0
+        best, restore = np.inf, None
         dev = torch.device("cuda", self.device_index)
         self.read(reset=True)
         for ep in range(int(epochs)):
@@ -277,25 +294,27 @@ class Trainer:
             loss = r["train_loss_sum"] / max(r["train_frames"], 1)
             hist.epoch.append(ep)
             hist.history["loss"].append(loss)
-            if xv is None:
-                if verbose:
-                    print(f"Epoch {ep + 1}/{epochs} - loss: {loss:.4f}")
-                continue
-            val = r["eval_loss_sum"] / max(r["eval_frames"], 1)
-            hist.history["val_loss"].append(val)
+            val = r["eval_loss_sum"] / max(r["eval_frames"], 1) if xv is not None else None
+            logs = {"loss": loss, "val_loss": val}
+            if val is not None:
+                hist.history["val_loss"].append(val)
             if verbose:
-                print(f"Epoch {ep + 1}/{epochs} - loss: {loss:.4f} - val_loss: {val:.4f}")
-            if val < best:
-                best, wait, hist.best_epoch = val, 0, ep
+                print(f"Epoch {ep + 1}/{epochs} - loss: {loss:.4f}" + (f" - val_loss: {val:.4f}" if val is not None else ""))
+            if val is not None and val < best:
+                best, hist.best_epoch = val, ep
                 hist.best_weights = self.get_weights()
                 if on_best is not None:
                     on_best(ep, val, self)
-                if checkpoint is not None:
-                    self.save(checkpoint)
-            else:
-                wait += 1
-                if patience is not None and wait >= patience:
-                    hist.stopped_epoch = ep
+            if ckpt is not None and ckpt.should_save(logs[ckpt.monitor]):
+                self.save(ckpt.filepath)
+            if stop is not None:
+                improved, halt = stop.update(logs[stop.monitor])
+                if improved and stop.restore_best_weights:
+                    restore = self.get_weights()
+                if halt:
+                    hist.stopped_epoch = stop.stopped_epoch = ep
+                    if stop.restore_best_weights and restore is not None:
+                        self.set_weights(restore)
                     break
         if xv is None:
             hist.history.pop("val_loss")
