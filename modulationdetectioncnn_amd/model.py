@@ -366,6 +366,13 @@ class VTCNN2:
         captured from this model's forwards has been destroyed: a replay after this writes through a stale address."""
         self._ws_captured = []
 
+    def build(self, input_shape=None) -> None:
+        """``model.build()`` (cnn.py:114): the topology fixes every shape already."""
+
+    def summary(self) -> None:
+        """``model.summary()`` (cnn.py:115) prints the layer table."""
+        print(self.topology.summary())
+
     # ------------------------------------------------------------------ model.layers / model.inputs (CNN.ipynb cells 15, 17)
     @property
     def layers(self) -> List["Layer"]:
