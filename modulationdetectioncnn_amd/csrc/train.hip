@@ -150,21 +150,34 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
     for (int f = 0; f < F; ++f) { k0[f] = params[f]; k1[f] = params[F + f]; cb[f] = params[offCb + f]; }
 #pragma unroll
     for (int c = 0; c < C; ++c) bd[c] = params[offBd + c];
-    // dense kernel row of (h, w, f): h*129F + w*F + f   (channels_last Flatten)
+    // dense kernel row of (h, w, f): h*129F + w*F + f   (channels_last Flatten).  A lane's positions w = 4l'..4l'+3 are ONE
+    // contiguous run of 4 F C floats (entry (s, f, c) at (s F + f) C + c), lane 31's position 128 the F C floats behind its run:
+    // the run is fetched (and its gradient written) as 16-byte pieces -- a quarter of the instructions and line requests of
+    // one dword per entry across 64 lanes 4 F C floats apart (4-byte aligned only: row 1 starts 129 F C floats in).
+    struct __attribute__((packed, aligned(4))) Run4 { float v[4]; };
+    constexpr int FC = F * C, RUN = 4 * FC;
+    static_assert(RUN % 4 == 0, "a lane's run is whole 16-byte pieces");
+    const long run0 = offWd + (long)(h * 129 + 4 * lp) * FC;
     float Wr[WLDS ? 1 : S][WLDS ? 1 : F][WLDS ? 1 : C], dW[GRAD ? S : 1][GRAD ? F : 1][GRAD ? C : 1];
+    auto put = [&](int e, float v) {       // e: compile-time entry index (s F + f) C + c
+        if (WLDS) sW[e * 64 + lane] = v;   // (read back by this lane only: no barrier needed)
+        else Wr[WLDS ? 0 : e / FC][WLDS ? 0 : (e / C) % F][WLDS ? 0 : e % C] = v;
+    };
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int w = s < 4 ? 4 * lp + s : 128;
-        const bool mine = s < 4 || lp == 31;
+    for (int q = 0; q < RUN / 4; ++q) {
+        const Run4 r = *reinterpret_cast<const Run4*>(params + run0 + 4 * q);
 #pragma unroll
-        for (int f = 0; f < F; ++f)
+        for (int i = 0; i < 4; ++i) put(4 * q + i, r.v[i]);
+    }
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float v = mine ? params[offWd + ((h * 129 + w) * F + f) * C + c] : 0.f;
-                if (WLDS) sW[((s * F + f) * C + c) * 64 + lane] = v;      // (read back by this lane only: no barrier needed)
-                else Wr[s][f][c] = v;
-                if (GRAD) dW[s][f][c] = 0.f;
-            }
+    for (int e = 0; e < FC; ++e) put(RUN + e, lp == 31 ? params[run0 + RUN + e] : 0.f);
+    if (GRAD) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int c = 0; c < C; ++c) dW[s][f][c] = 0.f;
     }
     auto Wv = [&](int s, int f, int c) -> float { return WLDS ? sW[((s * F + f) * C + c) * 64 + lane] : Wr[WLDS ? 0 : s][WLDS ? 0 : f][WLDS ? 0 : c]; };
     float gk0[F], gk1[F], gcb[F], gbd[C];
@@ -254,14 +267,17 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
     if (lane == 0) loss_partials[g] = loss;
     if (!GRAD) return;
     float* out = partials + (size_t)g * P;
+    auto dWe = [&](int e) -> float { return dW[GRAD ? e / FC : 0][GRAD ? (e / C) % F : 0][GRAD ? e % C : 0]; };
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int w = s < 4 ? 4 * lp + s : 128;
-        if (s < 4 || lp == 31)
+    for (int q = 0; q < RUN / 4; ++q) {
+        Run4 r;
 #pragma unroll
-            for (int f = 0; f < F; ++f)
+        for (int i = 0; i < 4; ++i) r.v[i] = dWe(4 * q + i);
+        *reinterpret_cast<Run4*>(out + run0 + 4 * q) = r;
+    }
+    if (lp == 31) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) out[offWd + ((h * 129 + w) * F + f) * C + c] = dW[GRAD ? s : 0][GRAD ? f : 0][GRAD ? c : 0];
+        for (int e = 0; e < FC; ++e) out[run0 + RUN + e] = dWe(RUN + e);
     }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
