@@ -9,8 +9,16 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_repeated_forwards_are_bit_identical():
+def _soak():
     spec = importlib.util.spec_from_file_location("soak", os.path.join(ROOT, "tools", "soak.py"))
     soak = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(soak)
-    assert soak.run(reps=40, log=lambda *a, **k: None) == []
+    return soak
+
+
+def test_repeated_forwards_are_bit_identical():
+    assert _soak().run(reps=40, log=lambda *a, **k: None) == []
+
+
+def test_repeated_training_epochs_are_bit_identical():
+    assert _soak().run_training(reps=6, log=lambda *a, **k: None) == []
