@@ -449,3 +449,22 @@ def test_dropout_through_the_mirror_and_its_refusals():
     L = _cabi.lib()
     assert L.mdc_trainer_set_dropout(m.trainer()._h, 1.0, 0) == -22 and L.mdc_trainer_set_dropout(m.trainer()._h, -0.1, 0) == -22
     assert L.mdc_trainer_set_dropout(None, 0.5, 0) == -22
+
+
+def test_first_epoch_of_a_fresh_cnn_py_model_starts_where_the_recorded_run_did():
+    """The one training run the reference recorded (cnn.ipynb cell 6's output: cnn.py's net, 5 classes, 22,500 frames, 22 batches
+    of 1,024 per epoch) begins `Epoch 1/150 - loss: 1.6028 - val_loss: 1.5949`: a freshly initialised net (glorot_uniform
+    conv, he_normal dense, zero biases) on frames of the data set's scale puts its logits near zero, so the first epoch's
+    running loss sits just under ln 5 = 1.6094.  The data set is not here, so this is an anchor, not parity: the same
+    definition on frames of that scale must start within 0.02 of the recorded figure, in 22 steps, the last batch short."""
+    import math
+    topo = Topology.cnnpy(10, 10, 5)
+    n = 22500
+    from modulationdetectioncnn_amd import synthetic_frames
+    x = synthetic_frames(n + 2000, seed=7, sigma=7e-3)                    # RML2016.10a frames are unit-energy: |x| ~ 1e-2
+    lab = np.random.default_rng(7).integers(0, 5, n + 2000)
+    m = VTCNN2.synthetic(topo, seed=2016, device=0)
+    m.compile(loss='categorical_crossentropy', optimizer='adam')
+    h = m.fit(x[:n], to_onehot(lab[:n], 5), batch_size=1024, epochs=1, validation_data=(x[n:], to_onehot(lab[n:], 5)), seed=0)
+    assert m.trainer().read(reset=False)["iterations"] == 22            # `22/22` in the recorded log
+    assert abs(h.history["loss"][0] - 1.6028) < 0.02 and abs(h.history["val_loss"][0] - math.log(5)) < 0.02
