@@ -27,11 +27,14 @@ layer semantics restated are: ZeroPadding2D((0,p)) pads W only; Conv2D is
 cross-correlation, 'valid', stride 1, HWIO kernel; Flatten is C-order over the
 layer's output tensor; Dense is x@W+b; softmax is exp(x-max)/sum.
 
-PINNING: tests/test_oracle_golden.py checks this file against the two Keras
-outputs recorded in the reference (CNN.ipynb cell 18 and
-12.16.testDataYunyun.txt:1-2, :263-264).  T2/T3/T4 have no recorded outputs:
-for them this oracle is "parity unpinned" (cross-checked only against an
-independent torch-CPU statement in tests/test_oracle_crosscheck.py).
+PINNING: tests/test_oracle_golden.py checks this file against the Keras
+outputs recorded in the reference: T1's Dense output (CNN.ipynb cell 18 and
+12.16.testDataYunyun.txt:1-2, :263-264) and, for T2 with the bundled 10-filter
+checkpoint, 21 entries of its Flatten output (CNN.ipynb cell 19: three input
+samples explain all of them; eighteen are predictions, met to the printed
+digits).  T2's Dense layer, T3 and T4 have no recorded outputs: for them this
+oracle is "parity unpinned" (cross-checked only against an independent
+torch-CPU statement in tests/test_oracle_crosscheck.py).
 """
 from __future__ import annotations
 

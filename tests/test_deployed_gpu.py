@@ -53,6 +53,22 @@ def test_keras_known_answer_on_gpu():
     np.testing.assert_allclose(m.predict(x)[0], [0.67148, 0.24728, 0.08124], atol=1e-5)
 
 
+def test_keras_known_answer_t2_flatten_entries_on_gpu():
+    """CNN.ipynb cell 19: 21 entries of the 10-filter net's Flatten output as Keras printed them (the bundled convmodrecnets
+    checkpoint; tests/test_oracle_golden.py derives the three input samples they imply and explains the fixture).  The HIP
+    tap kernels reproduce the eighteen entries that are predictions to the printed digits, inside a batch as alone."""
+    from test_oracle_golden import _t2_flat_kat, t2_kat_frame
+    idx, want = _t2_flat_kat()
+    x, _samples = t2_kat_frame()
+    m = _model("convmodrecnets_CNN2_0.5")
+    flat = m.predict(x, tap="flat")
+    assert flat.shape == (1, 2580) and np.abs(flat[0, idx] - want).max() < 2.5e-8
+    conv = m.predict(x, tap="conv")                                    # model4 = layers[2].output: (1, 2, 129, 10)
+    assert np.array_equal(conv.reshape(1, -1), flat)
+    xb = np.concatenate([synthetic_frames(37, seed=3, sigma=5e-3), x, synthetic_frames(90, seed=4, sigma=5e-3)])
+    assert np.array_equal(m.predict(xb, tap="flat")[37], flat[0])
+
+
 @pytest.mark.parametrize("name", H5_NAMES)
 def test_bundled_frames_all_checkpoints(name):
     x, meta = _frames()

@@ -100,3 +100,54 @@ def test_empty_batch():
     w = _flat(load_deployed_npz("3convmodrecnets_CNN2_0.5"))
     r = O.forward_deployed(np.zeros((0, 2, 128), np.float32), *w)
     assert r["probs"].shape == (0, 3) and r["labels"].shape == (0,)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# T2 (the bundled 10-filter checkpoint): CNN.ipynb cell 19 prints 21 entries of a Flatten output (model3 = layers[3].output,
+# 2,580 values) that Keras computed in a session whose input frame the notebook does not show.  Flat index h*1290 + w*10 + f:
+#   0..9    = relu(b[f] + K1[f] I[0])                      (w = 0: the left neighbour is ZeroPadding2D's zero)
+#   10..17  = relu(b[f] + K0[f] I[0] + K1[f] I[1])         (w = 1, f = 0..7)
+#   2577..9 = relu(b[f] + K0[f] Q[127])                    (h = 1, w = 128, f = 7..9: the right neighbour is the padding's zero)
+# Three unknown samples, 21 recorded numbers: fit the samples on three entries, PREDICT the other eighteen.  That they come out to
+# the printed digits pins -- against Keras' own arithmetic, on the bundled weights -- the .h5 reader's conv kernel and bias, the
+# kernel's tap order (K[0,0] on x[w-1], K[0,1] on x[w]), the padding, the ReLU (two entries are exact zeros) and the
+# channels_last Flatten order; the dense layer of T2 stays unpinned.
+# ---------------------------------------------------------------------------------------------------------------------
+def _t2_flat_kat():
+    k = json.load(open(os.path.join(GOLDEN, "keras_kat_t2_flat.json")))
+    return np.asarray(k["flat_index"]), np.asarray(k["keras_flat"], np.float64)
+
+
+def t2_kat_frame():
+    """The (1,2,128) frame whose I[0], I[1], Q[127] are the samples three of the recorded entries imply (all else zero)."""
+    idx, val = _t2_flat_kat()
+    rec = dict(zip(idx.tolist(), val.tolist()))
+    w = load_deployed_npz("convmodrecnets_CNN2_0.5")
+    K, b = w[0][0].astype(np.float64), w[0][1].astype(np.float64)
+    k0, k1 = K[0, 0, 0], K[0, 1, 0]
+    i0 = (rec[1] - b[1]) / k1[1]                                   # entry (w=0, f=1)
+    i1 = (rec[11] - b[1] - k0[1] * i0) / k1[1]                     # entry (w=1, f=1)
+    q127 = (rec[2577] - b[7]) / k0[7]                              # entry (h=1, w=128, f=7)
+    x = np.zeros((1, 2, 128), np.float32)
+    x[0, 0, 0], x[0, 0, 1], x[0, 1, 127] = i0, i1, q127
+    return x, (i0, i1, q127)
+
+
+def test_keras_known_answer_t2_flatten_entries():
+    idx, want = _t2_flat_kat()
+    x, (i0, i1, q127) = t2_kat_frame()
+    assert 1e-3 < abs(i0) < 2e-2 and 1e-3 < abs(i1) < 2e-2 and 1e-3 < abs(q127) < 2e-2      # plausible I/Q samples of the data set's scale
+    w = _flat(load_deployed_npz("convmodrecnets_CNN2_0.5"))
+    assert w[0].shape == (1, 2, 1, 10)
+    for dtype, tol in ((np.float64, 1.5e-8), (np.float32, 2.5e-8)):       # printed to 8 significant digits (the last three to 8 decimals)
+        flat = O.forward_deployed(x, *w, dtype=dtype)["flat"][0]
+        assert flat.shape == (2580,)
+        err = np.abs(flat[idx] - want)
+        assert err.max() < tol, (dtype, err.max(), idx[err.argmax()])
+    fitted = np.isin(idx, [1, 11, 2577])
+    assert (~fitted).sum() == 18 and (want[~fitted] == 0).sum() == 2       # eighteen predictions, two of them rectified zeros
+    # the convention is what is pinned: with the taps swapped (K[0,1] on the LEFT neighbour) the same fit misses the others by 1e-3
+    K = w[0].copy()
+    K[0, 0], K[0, 1] = w[0][0, 1].copy(), w[0][0, 0].copy()
+    wrong = O.forward_deployed(x, K, *w[1:], dtype=np.float64)["flat"][0]
+    assert np.abs(wrong[idx] - want).max() > 1e-3

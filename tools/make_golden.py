@@ -6,6 +6,8 @@ Reads (never executes) under /root/reference:
   * the fifteen Q6.12 frame .txt files         -> golden/frames.npz + frames.json
   * the seven Q6.12 weight .txt files          -> golden/weights_txt/<name>.npz
   * CNN.ipynb cell 18 stored output (text)     -> golden/keras_kat.json  (float input + Keras answer)
+  * CNN.ipynb cell 19 stored output (text)     -> golden/keras_kat_t2_flat.json  (21 entries of the 10-filter net's Flatten
+                                                  output as Keras printed them; the input frame was not printed)
   * the "* prediction:" comments of 12.16.testDataYunyun.txt -> frames.json
   * the three stored model.summary() printouts (CNN.ipynb cell 6 = T1, cnn.ipynb = T4, the DeepSig notebook = T3)
                                                -> golden/summaries.json (layer kinds, output shapes, parameter counts)
@@ -52,6 +54,27 @@ def cell18():
     pred = [float(t) for t in re.findall(r"-?\d+\.\d+", tail)]
     assert len(pred) == 3, pred
     return np.asarray(nums, np.float32).reshape(1, 2, 128), pred, cell.get("execution_count")
+
+
+def cell19():
+    """`print(output_conv_relu[0])` + the element prints of CNN.ipynb cell 19: output_conv_relu = model3.predict(...) is the Flatten
+    output (2,580 values: a 10-filter net) of a session whose input frame is not in the notebook.  -> {flat index: value}."""
+    nb = json.load(open(os.path.join(REF, "CNN.ipynb")))
+    cell = nb["cells"][19]
+    text = "".join("".join(o.get("text", "")) for o in cell["outputs"])
+    lines = text.split("\n")
+    arr = [float(t) for t in re.findall(r"\d+\.\d*(?:e[-+]?\d+)?", lines[0])]            # [a b c ... x y z]: numpy's summary of 2,580 values
+    assert len(arr) == 6 and "..." in lines[0], lines[0]
+    first = [float(v) for v in lines[lines.index("First 10 Values") + 1: lines.index("next 10")]]
+    nxt = [float(v) for v in lines[lines.index("next 10") + 1: lines.index("Last Value")]]
+    last = float(lines[lines.index("Last Value") + 1])
+    assert len(first) == 10 and len(nxt) == 8, (first, nxt)
+    # the summary line prints the same leading values to fewer digits: they must agree with the element prints
+    assert all(abs(a - b) < 1e-8 for a, b in zip(arr[:3], first[:3])) and abs(arr[5] - last) < 1e-8
+    vals = {i: v for i, v in enumerate(first)}
+    vals.update({10 + i: v for i, v in enumerate(nxt)})
+    vals.update({2577: arr[3], 2578: arr[4], 2579: last})
+    return vals, cell.get("execution_count")
 
 
 SUMMARIES = {      # topology tag -> (notebook, how the build names it)
@@ -135,6 +158,14 @@ def main():
                "weights": "3convmodrecnets_CNN2_0.5", "tap": "dense (model2 = layers[4].output, post-ReLU, pre-softmax)",
                "input": [float(np.float32(v)) for v in x.ravel()], "keras_dense": pred},
               open(os.path.join(OUT, "keras_kat.json"), "w"))
+    vals, exe19 = cell19()
+    json.dump({"source": "CNN.ipynb cell 19 stored output (execution_count %s): entries of output_conv_relu[0] = model3.predict(...)[0]" % exe19,
+               "weights": "convmodrecnets_CNN2_0.5 (the bundled 10-filter checkpoint: the 21 entries are mutually consistent under ITS conv "
+                          "kernel and bias -- three input samples explain all of them, tests/test_oracle_golden.py)",
+               "tap": "flat (model3 = layers[3].output: Conv2D + ReLU, flattened channels_last, index h*1290 + w*10 + f)",
+               "input": "not printed in the notebook; three of its samples (I[0], I[1], Q[127]) follow from three of the entries",
+               "flat_index": sorted(vals), "keras_flat": [vals[i] for i in sorted(vals)]},
+              open(os.path.join(OUT, "keras_kat_t2_flat.json"), "w"), indent=1)
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
     json.dump(stored_summaries(), open(os.path.join(OUT, "summaries.json"), "w"), indent=1)
     print("wrote", OUT)
