@@ -60,6 +60,10 @@ def test_float2fix_roundtrip_and_bug():
         bits = q612.float2fix(v)
         assert len(bits) == 18
         assert q612.bits_to_int(bits) == int(v * 4096)
+    # recorded by the reference itself: CNN.ipynb cell 21 prints output_dense[0] = [3.510959 3.1282985 4.310499] and cell 25 their
+    # float2fix(x, 18, 12) strings
+    for v, bits in ((3.510959, "000011100000101100"), (3.1282985, "000011001000001101"), (4.310499, "000100010011110111")):
+        assert q612.float2fix(v) == bits
     # the reference generator's negative-zero bug (CNN.ipynb cell 23): 19 characters
     assert q612.float2fix(-1e-5, bug_compatible=True) == q612.NEGZERO_19
     assert q612.float2fix(-1e-5) == "0" * 18
