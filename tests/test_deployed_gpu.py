@@ -70,6 +70,26 @@ def test_keras_known_answer_t2_flatten_entries_on_gpu():
 
 
 @pytest.mark.parametrize("name", H5_NAMES)
+def test_the_two_unquantised_data_set_frames_the_notebook_prints(name):
+    """CNN.ipynb cells 14 / 16 print X_test[2] and X_test[3] in full float precision -- the only unquantised RML2016.10a frames in the
+    reference besides cell 18's (tests/golden/notebook_frames.npz).  No Keras output is recorded for them: held to the f64 oracle,
+    every checkpoint, every precision mode's label."""
+    x = np.load(os.path.join(GOLDEN, "notebook_frames.npz"))["frames"]
+    assert x.shape == (2, 2, 128) and 4e-3 < x.std() < 6e-3             # the scale bench.py's synthetic frames are drawn at (sigma 5e-3)
+    w = [a for p in load_deployed_npz(name) for a in p]
+    ref = O.forward_deployed(x, *w, dtype=np.float64)
+    m = _model(name)
+    np.testing.assert_allclose(m.predict(x), ref["probs"], atol=2e-6)
+    np.testing.assert_allclose(m.predict(x, tap="dense"), ref["dense"], rtol=0, atol=5e-6)
+    assert m.predict_classes(x).tolist() == ref["labels"].tolist()
+    margin = np.sort(ref["dense"], axis=1)[:, -1] - np.sort(ref["dense"], axis=1)[:, -2]
+    for dtype in ("bf16", "f16", "fp8"):
+        lab = VTCNN2.from_npz(os.path.join(GOLDEN, "weights", name + ".npz"), dtype=dtype).predict_classes(x)
+        decided = margin > 0.15 * np.abs(ref["dense"]).max()
+        assert (lab[decided] == ref["labels"][decided]).all(), (dtype, lab, ref["labels"], margin)
+
+
+@pytest.mark.parametrize("name", H5_NAMES)
 def test_bundled_frames_all_checkpoints(name):
     x, meta = _frames()
     fz = json.load(open(os.path.join(GOLDEN, "oracle_frozen.json")))["by_weights"][name]

@@ -77,6 +77,20 @@ def cell19():
     return vals, cell.get("execution_count")
 
 
+def printed_frames():
+    """CNN.ipynb cells 14 and 16 print two frames of the data set in full float precision (`print(X_test[2])`, `print(X_test[3][0])` /
+    `[1]`): the only unquantised RML2016.10a frames the reference holds besides cell 18's.  -> (2, 2, 128) float32."""
+    nb = json.load(open(os.path.join(REF, "CNN.ipynb")))
+    num = r"-?\d+\.\d*(?:e[-+]?\d+)?"
+    t14 = "".join("".join(o.get("text", "")) for o in nb["cells"][14]["outputs"])
+    t16 = "".join("".join(o.get("text", "")) for o in nb["cells"][16]["outputs"])
+    a = [float(t) for t in re.findall(num, t14)]
+    i16, q16 = t16.split("Q Data (128)")
+    b = [float(t) for t in re.findall(num, i16.split("I Data (128)")[1])] + [float(t) for t in re.findall(num, q16)]
+    assert len(a) == 256 and len(b) == 256, (len(a), len(b))
+    return np.asarray([a, b], np.float32).reshape(2, 2, 128)
+
+
 SUMMARIES = {      # topology tag -> (notebook, how the build names it)
     "deployed3": "CNN.ipynb",
     "cnnpy": "cnn.ipynb",
@@ -158,6 +172,8 @@ def main():
                "weights": "3convmodrecnets_CNN2_0.5", "tap": "dense (model2 = layers[4].output, post-ReLU, pre-softmax)",
                "input": [float(np.float32(v)) for v in x.ravel()], "keras_dense": pred},
               open(os.path.join(OUT, "keras_kat.json"), "w"))
+    np.savez(os.path.join(OUT, "notebook_frames.npz"), frames=printed_frames(),
+             source=np.array("CNN.ipynb cells 14 (X_test[2]) and 16 (X_test[3]): stored print output, float32 as printed"))
     vals, exe19 = cell19()
     json.dump({"source": "CNN.ipynb cell 19 stored output (execution_count %s): entries of output_conv_relu[0] = model3.predict(...)[0]" % exe19,
                "weights": "convmodrecnets_CNN2_0.5 (the bundled 10-filter checkpoint: the 21 entries are mutually consistent under ITS conv "
