@@ -86,8 +86,8 @@ int main(int argc, char** argv) {
         for (long i = 0; i < n; ++i) order[i] = (int32_t)((7919L * i + 13L * ep) % n);
         HIP_CHECK(hipMemcpyAsync(order_dev, order, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
         for (long first = 0; first < n; first += batch)                                     /* model.fit: one step per batch   cnn.py:135 */
-            MDC_CHECK(mdc_train_batch(t, x_dev, y_dev, order_dev, first, n - first < batch ? n - first : batch, 1, s));
-        MDC_CHECK(mdc_trainer_evaluate(t, x_dev + (size_t)n * 256, y_dev + (size_t)n * 3, NULL, 0, nv, s));      /* validation_data  cnn.py:140 */
+            MDC_CHECK(mdc_train_batch(t, x_dev, y_dev, n, order_dev, first, n - first < batch ? n - first : batch, 1, s));
+        MDC_CHECK(mdc_trainer_evaluate(t, x_dev + (size_t)n * 256, y_dev + (size_t)n * 3, nv, NULL, 0, nv, s));      /* validation_data  cnn.py:140 */
         double tl = 0, vl = 0;
         int64_t tf = 0, vf = 0, it = 0;
         MDC_CHECK(mdc_trainer_read(t, 1, &tl, &tf, &vl, &vf, &it, s));                        /* the epoch's one synchronisation */

@@ -274,8 +274,10 @@ MDC_API int mdc_profile_reset(mdc_model* m);
  * Everything below runs on the trainer's device; x_dev (frames (., 2, 128) f32, 16-byte aligned) and y_dev (target rows
  * (., classes) f32: the one-hot rows of cnn.py:74-82, or any distribution) are the caller's buffers holding the WHOLE set;
  * a mini-batch is the frames order_dev[first .. first + count) of it (order_dev: int32 indices on the device, the
- * epoch's shuffle -- frames are never moved; NULL = the identity; every index must address a frame of the buffers: the
- * library cannot check device memory).  mdc_train_batch and mdc_trainer_evaluate only enqueue
+ * epoch's shuffle -- frames are never moved; NULL = the identity).  n_frames is how many frames the two buffers hold: a
+ * position whose index lies outside [0, n_frames) is SKIPPED on the device -- it adds nothing to the loss or the gradient
+ * (the batch mean still divides by count) -- and is counted; the next mdc_trainer_read then returns MDC_EINVAL with the count:
+ * a bad shuffle is an error at the epoch's read, never a GPU fault.  mdc_train_batch and mdc_trainer_evaluate only enqueue
  * on hip_stream (two launches, no synchronisation, no allocation: capturable in a hipGraph; Adam's step count lives on the
  * device).  A step is reproducible bit for bit (fixed-order reductions, no float atomics).  One stream at a time per trainer. */
 typedef struct mdc_trainer mdc_trainer;   /* opaque: f32 master weights in the Keras layouts, Adam state, scratch */
@@ -315,13 +317,13 @@ MDC_API int mdc_trainer_set_iterations(mdc_trainer* t, int64_t iterations, void*
 /* model.train_on_batch / one step of model.fit (cnn.py:135): forward, loss, backward over the `count` frames and, if
  * `apply` != 0, one Adam update (apply = 0: the gradient is computed and kept for MDC_TRAIN_GRADIENT, nothing changes).
  * The batch's summed loss and frame count are added to the trainer's running training statistics. */
-MDC_API int mdc_train_batch(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first,
-                    int64_t count, int apply, void* hip_stream);
+MDC_API int mdc_train_batch(mdc_trainer* t, const float* x_dev, const float* y_dev, int64_t n_frames, const int32_t* order_dev,
+                    int64_t first, int64_t count, int apply, void* hip_stream);
 
 /* The val_loss half of model.fit's epoch end / model.evaluate with the weights as they are now (cnn.py:140, 153): adds the
  * summed per-sample loss and the frame count to the trainer's evaluation statistics. */
-MDC_API int mdc_trainer_evaluate(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first,
-                         int64_t count, void* hip_stream);
+MDC_API int mdc_trainer_evaluate(mdc_trainer* t, const float* x_dev, const float* y_dev, int64_t n_frames, const int32_t* order_dev,
+                         int64_t first, int64_t count, void* hip_stream);
 
 /* Synchronise hip_stream and read the statistics (each pointer may be NULL): sums of per-sample losses and frame counts
  * since the last reset, for training batches and for evaluation (mean = sum / frames: fit's `loss` and `val_loss`), and

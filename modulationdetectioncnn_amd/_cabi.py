@@ -107,8 +107,8 @@ def lib(variant: str = "product") -> C.CDLL:
     L.mdc_trainer_set_tensor.argtypes = [vp, i32, i32, fp, sz, fp, sz, vp]
     L.mdc_trainer_get_tensor.argtypes = [vp, i32, i32, fp, sz, fp, sz, vp]
     L.mdc_trainer_set_iterations.argtypes = [vp, i64, vp]
-    L.mdc_train_batch.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp]
-    L.mdc_trainer_evaluate.argtypes = [vp, vp, vp, vp, i64, i64, vp]
+    L.mdc_train_batch.argtypes = [vp, vp, vp, i64, vp, i64, i64, i32, vp]
+    L.mdc_trainer_evaluate.argtypes = [vp, vp, vp, i64, vp, i64, i64, vp]
     L.mdc_trainer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64), vp]
     L.mdc_trainer_destroy.argtypes = [vp]
     L.mdc_trainer_destroy.restype = None

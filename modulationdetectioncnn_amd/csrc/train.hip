@@ -74,7 +74,7 @@ struct TrainState {
     long long eval_frames;
     double eval_loss;
     unsigned tickets;          // work-groups of the running reduce + Adam launch that have read `iterations` (the last one bumps it)
-    unsigned pad_;
+    unsigned bad_indices;      // frames skipped because their index (order_dev's, or first + i) lay outside [0, n_frames): mdc_trainer_read reports them
 };
 
 // The optional Dropout's counter-based generator (include/mdc.h, mdc_trainer_set_dropout; oracle/oracle_train.py restates it):
@@ -94,6 +94,16 @@ __device__ __forceinline__ unsigned drop_frame_key(unsigned kstep, long frame, u
 }
 __device__ __forceinline__ bool drop_keep(unsigned kframe, unsigned element, unsigned thr) {
     return fmix32(kframe + element * 0xC2B2AE35u) >= thr;
+}
+
+// The frame a batch position names, or -1 if that is no frame of the caller's buffers (a shuffle index out of range): such a
+// position is SKIPPED -- all-zero samples and targets contribute nothing to loss or gradient below -- and counted, once, by the
+// lane `count_it` names; mdc_trainer_read turns the count into an error.  An unchecked index would be a GPU fault instead.
+__device__ __forceinline__ long frame_index(const int* __restrict__ order, long first, int i, long n_frames, TrainState* st, bool count_it) {
+    const long idx = order ? (long)order[first + i] : first + i;
+    if ((unsigned long)idx < (unsigned long)n_frames) return idx;
+    if (count_it) atomicAdd(&st->bad_indices, 1u);
+    return -1;
 }
 
 __device__ __forceinline__ float wave_allsum(float v) {
@@ -137,9 +147,9 @@ __device__ __forceinline__ float softmax_xent(const float (&d)[CMAX], const floa
 // kernel of the 10-filter net would otherwise hold 150 weights + 150 gradient sums per lane and spill.
 template <int F, bool GRAD, bool WLDS, bool DROP = false>
 __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const int* __restrict__ order, long first, int count,
+                                                           long n_frames, const int* __restrict__ order, long first, int count,
                                                            const float* __restrict__ params, float* __restrict__ partials,
-                                                           double* __restrict__ loss_partials, const TrainState* __restrict__ st, DropArgs drop) {
+                                                           double* __restrict__ loss_partials, TrainState* __restrict__ st, DropArgs drop) {
     constexpr int C = 3, S = 5;
     constexpr int offCb = 2 * F, offWd = 3 * F, offBd = 3 * F + 258 * F * C, P = offBd + C;
     __shared__ float sW[WLDS ? S * F * C * 64 : 1];
@@ -192,11 +202,16 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
     // the sched_barrier keeps hipcc from sinking the loads to their first use)
     long idx_n = 0;
     auto fetch = [&](int i, float4& xv, float (&yv)[C]) {
-        const long idx = order ? (long)order[first + i] : first + i;
+        const long idx = frame_index(order, first, i, n_frames, st, lane == 0);
         idx_n = idx;
-        xv = *reinterpret_cast<const float4*>(x + idx * kFrameFloats + h * kSamples + 4 * lp);
+        xv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < C; ++c) yv[c] = y[idx * C + c];
+        for (int c = 0; c < C; ++c) yv[c] = 0.f;
+        if (idx >= 0) {
+            xv = *reinterpret_cast<const float4*>(x + idx * kFrameFloats + h * kSamples + 4 * lp);
+#pragma unroll
+            for (int c = 0; c < C; ++c) yv[c] = y[idx * C + c];
+        }
     };
     float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
     float yn[C] = {0.f, 0.f, 0.f};
@@ -309,10 +324,10 @@ constexpr int kT4Mc = 0, kT4Cb = 256 * 32, kT4W1 = kT4Cb + 32, kT4B1 = kT4W1 + 3
 constexpr int kT4Xld = kChainXld, kT4Yld = 36;
 
 template <bool GRAD, bool DROP = false>
-__global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ order,
-                                                        long first, int count, int F, int D, int C, const float* __restrict__ params,
-                                                        float* __restrict__ partials, double* __restrict__ loss_partials,
-                                                        const TrainState* __restrict__ st, DropArgs drop) {
+__global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict__ x, const float* __restrict__ y, long n_frames,
+                                                        const int* __restrict__ order, long first, int count, int F, int D, int C,
+                                                        const float* __restrict__ params, float* __restrict__ partials,
+                                                        double* __restrict__ loss_partials, TrainState* __restrict__ st, DropArgs drop) {
     const int A = 3 * F;
     const int offCb = 256 * F, offW1 = offCb + F, offB1 = offW1 + A * D, offW2 = offB1 + D, offB2 = offW2 + D * C;
     __shared__ __attribute__((aligned(16))) float xs[16 * kT4Xld];
@@ -368,8 +383,8 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
         for (int r = 0; r < 16; ++r) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f0 + r < count) {
-                const long idx = order ? (long)order[first + f0 + r] : first + f0 + r;
-                v = reinterpret_cast<const float4*>(x + idx * kFrameFloats)[lane];
+                const long idx = frame_index(order, first, f0 + r, n_frames, st, lane == 0);
+                if (idx >= 0) v = reinterpret_cast<const float4*>(x + idx * kFrameFloats)[lane];
             }
             *reinterpret_cast<float4*>(xs + r * kT4Xld + 4 * lane) = v;
         }
@@ -380,8 +395,8 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
             const int fi = f0 + 4 * g + r;
             yv[r] = 0.f;
             m0[0][r] = m0[1][r] = m1[r] = 1.f;
-            if (fi < count) {
-                const long idx = order ? (long)order[first + fi] : first + fi;
+            const long idx = fi < count ? frame_index(order, first, fi, n_frames, st, false) : -1;      // (counted where the frame is staged)
+            if (idx >= 0) {
                 if (cls) yv[r] = y[idx * C + fr];
                 if (DROP) {
                     const unsigned k0f = drop_frame_key(kstep, idx, 0u), k1f = drop_frame_key(kstep, idx, 1u);
@@ -664,16 +679,16 @@ int waves_for(const mdc_trainer* t, int64_t count) {
     return (int)g;
 }
 
-int launch_batch(mdc_trainer* t, const float* x, const float* y, const int32_t* order, int64_t first, int64_t count, int mode, hipStream_t s) {
+int launch_batch(mdc_trainer* t, const float* x, const float* y, int64_t n_frames, const int32_t* order, int64_t first, int64_t count, int mode, hipStream_t s) {
     const int G = waves_for(t, count);
     auto* st = static_cast<TrainState*>(t->d_state);
     const int cnt = (int)count;
     // Dropout acts in training batches only (mode != 0: Keras' fit reports the loss WITH it, evaluates val_loss without)
     const bool drop_on = mode != 0 && t->drop_rate > 0.f;
     const DropArgs drop{t->drop_seed, (unsigned)std::floor((double)t->drop_rate * 4294967296.0), 1.f / (1.f - t->drop_rate)};
-#define MDC_TRAIN_DEP(F, GR, WL, DR) hipLaunchKernelGGL((train_deployed_kernel<F, GR, WL, DR>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, \
+#define MDC_TRAIN_DEP(F, GR, WL, DR) hipLaunchKernelGGL((train_deployed_kernel<F, GR, WL, DR>), dim3(G), dim3(64), 0, s, x, y, (long)n_frames, order, (long)first, cnt, \
                                                          t->d_params, t->d_partials, t->d_loss_partials, st, drop)
-#define MDC_TRAIN_T4(GR, DR) hipLaunchKernelGGL((train_cnnpy_kernel<GR, DR>), dim3(G), dim3(64), 0, s, x, y, order, (long)first, cnt, t->topo.filters, \
+#define MDC_TRAIN_T4(GR, DR) hipLaunchKernelGGL((train_cnnpy_kernel<GR, DR>), dim3(G), dim3(64), 0, s, x, y, (long)n_frames, order, (long)first, cnt, t->topo.filters, \
                                                  t->topo.hidden, t->topo.classes, t->d_params, t->d_partials, t->d_loss_partials, st, drop)
     if (t->topo.kind == MDC_KIND_DEPLOYED) {
         if (t->topo.filters == 3) {
@@ -701,7 +716,8 @@ int launch_batch(mdc_trainer* t, const float* x, const float* y, const int32_t* 
     return MDC_OK;
 }
 
-int check_batch_args(const char* what, mdc_trainer* t, const float* x, const float* y, int64_t first, int64_t count) {
+int check_batch_args(const char* what, mdc_trainer* t, const float* x, const float* y, int64_t n_frames, const int32_t* order, int64_t first,
+                     int64_t count) {
     if (!t) { set_error("%s: null trainer", what); return MDC_EINVAL; }
     for (int l = 0; l < t->nlayers; ++l)
         if (!t->have[l]) { set_error("%s: layer %d has no weights (mdc_trainer_set_weights)", what, l); return MDC_ESTATE; }
@@ -709,6 +725,12 @@ int check_batch_args(const char* what, mdc_trainer* t, const float* x, const flo
     if (count > (int64_t)1 << 30) { set_error("%s: at most 2^30 frames per call", what); return MDC_EINVAL; }
     if (count > 0 && (!x || !y)) { set_error("%s: null frames or targets", what); return MDC_EINVAL; }
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) { set_error("%s: frames must be 16-byte aligned", what); return MDC_EINVAL; }
+    if (n_frames < 0) { set_error("%s: negative n_frames", what); return MDC_EINVAL; }
+    // without a shuffle the positions ARE the frames: checked here; with one, its VALUES are checked on the device (frame_index)
+    if (!order && first + count > n_frames) {
+        set_error("%s: frames [%lld, %lld) outside the %lld of the buffers", what, (long long)first, (long long)(first + count), (long long)n_frames);
+        return MDC_EINVAL;
+    }
     return MDC_OK;
 }
 
@@ -865,27 +887,27 @@ int mdc_trainer_set_iterations(mdc_trainer* t, int64_t iterations, void* hip_str
     });
 }
 
-int mdc_train_batch(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first, int64_t count, int apply,
-                    void* hip_stream) {
+int mdc_train_batch(mdc_trainer* t, const float* x_dev, const float* y_dev, int64_t n_frames, const int32_t* order_dev, int64_t first,
+                    int64_t count, int apply, void* hip_stream) {
     return guarded("mdc_train_batch", [&]() -> int {
-        int rc = check_batch_args("mdc_train_batch", t, x_dev, y_dev, first, count);
+        int rc = check_batch_args("mdc_train_batch", t, x_dev, y_dev, n_frames, order_dev, first, count);
         if (rc != MDC_OK) return rc;
         if (count == 0) return MDC_OK;
         DeviceScope dev(t->device);
         if (!dev.ok) { set_error("mdc_train_batch: cannot select device %d", t->device); return MDC_EIO; }
-        return launch_batch(t, x_dev, y_dev, order_dev, first, count, apply ? 2 : 1, static_cast<hipStream_t>(hip_stream));
+        return launch_batch(t, x_dev, y_dev, n_frames, order_dev, first, count, apply ? 2 : 1, static_cast<hipStream_t>(hip_stream));
     });
 }
 
-int mdc_trainer_evaluate(mdc_trainer* t, const float* x_dev, const float* y_dev, const int32_t* order_dev, int64_t first, int64_t count,
-                         void* hip_stream) {
+int mdc_trainer_evaluate(mdc_trainer* t, const float* x_dev, const float* y_dev, int64_t n_frames, const int32_t* order_dev, int64_t first,
+                         int64_t count, void* hip_stream) {
     return guarded("mdc_trainer_evaluate", [&]() -> int {
-        int rc = check_batch_args("mdc_trainer_evaluate", t, x_dev, y_dev, first, count);
+        int rc = check_batch_args("mdc_trainer_evaluate", t, x_dev, y_dev, n_frames, order_dev, first, count);
         if (rc != MDC_OK) return rc;
         if (count == 0) return MDC_OK;
         DeviceScope dev(t->device);
         if (!dev.ok) { set_error("mdc_trainer_evaluate: cannot select device %d", t->device); return MDC_EIO; }
-        return launch_batch(t, x_dev, y_dev, order_dev, first, count, 0, static_cast<hipStream_t>(hip_stream));
+        return launch_batch(t, x_dev, y_dev, n_frames, order_dev, first, count, 0, static_cast<hipStream_t>(hip_stream));
     });
 }
 
@@ -909,6 +931,10 @@ int mdc_trainer_read(mdc_trainer* t, int reset, double* train_loss_sum, int64_t*
             MDC_HIP(hipMemsetAsync(reinterpret_cast<char*>(t->d_state) + offsetof(TrainState, train_frames), 0,
                                    sizeof(TrainState) - offsetof(TrainState, train_frames), s));
             MDC_HIP(hipStreamSynchronize(s));
+        }
+        if (h.bad_indices) {      // (the statistics above are those of the frames that WERE addressable)
+            set_error("mdc_trainer_read: %u batch positions named frames outside [0, n_frames) -- skipped, not trained on; check order_dev", h.bad_indices);
+            return MDC_EINVAL;
         }
         return MDC_OK;
     });

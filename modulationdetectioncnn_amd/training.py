@@ -182,8 +182,9 @@ class Trainer:
     # ------------------------------------------------------------------ steps
     def _resident(self, x, y, order=None) -> None:
         """The raw pointers below are dereferenced by the kernels: refuse anything that is not a contiguous tensor of the expected
-        type in THIS device's memory (a host tensor's data_ptr() would be a GPU fault, not an error).  The VALUES of `order` are the
-        caller's to keep inside [0, len(x)) -- fit() checks the permutations it is given on the host."""
+        type in THIS device's memory (a host tensor's data_ptr() would be a GPU fault, not an error).  The VALUES of `order` are
+        checked where they are read, on the device: a position that names no frame of x is skipped and the next read() raises
+        (fit() also checks the permutations it is given on the host, before anything is enqueued)."""
         torch = _torch()
         want = (("frames", x, torch.float32, (2, 128)), ("targets", y, torch.float32, (self.topology.classes,)))
         for name, t, dt, tail in want + ((("order", order, torch.int32, ()),) if order is not None else ()):
@@ -200,12 +201,12 @@ class Trainer:
         count = n - first if count is None else int(count)
         if first < 0 or count < 0 or first + count > n:
             raise ValueError(f"batch [{first}, {first + count}) outside the {n} frames")
-        self._check(self._lib().mdc_train_batch(self._h, x.data_ptr(), y.data_ptr(), order.data_ptr() if order is not None else None,
+        self._check(self._lib().mdc_train_batch(self._h, x.data_ptr(), y.data_ptr(), x.shape[0], order.data_ptr() if order is not None else None,
                                                 first, count, int(apply), self._stream()))
 
     def evaluate_enqueue(self, x, y) -> None:
         self._resident(x, y)
-        self._check(self._lib().mdc_trainer_evaluate(self._h, x.data_ptr(), y.data_ptr(), None, 0, x.shape[0], self._stream()))
+        self._check(self._lib().mdc_trainer_evaluate(self._h, x.data_ptr(), y.data_ptr(), x.shape[0], None, 0, x.shape[0], self._stream()))
 
     def read(self, reset: bool = True) -> Dict:
         tl, el = C.c_double(), C.c_double()

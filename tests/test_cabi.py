@@ -42,8 +42,8 @@ def test_trainer_entry_points_validate_their_arguments_without_gpu():
     L = _cabi.lib()
     L.mdc_last_error.restype = ctypes.c_char_p
     assert L.mdc_trainer_create(None, 0, None) == -22 and b"null" in L.mdc_last_error()
-    assert L.mdc_train_batch(None, None, None, None, 0, 1, 1, None) == -22 and b"null trainer" in L.mdc_last_error()
-    assert L.mdc_trainer_evaluate(None, None, None, None, 0, 1, None) == -22
+    assert L.mdc_train_batch(None, None, None, 1, None, 0, 1, 1, None) == -22 and b"null trainer" in L.mdc_last_error()
+    assert L.mdc_trainer_evaluate(None, None, None, 1, None, 0, 1, None) == -22
     assert L.mdc_trainer_num_layers(None) == -22
     assert L.mdc_trainer_set_adam(None, 1e-3, 0.9, 0.999, 1e-7) == -22
     assert L.mdc_trainer_set_dropout(None, 0.5, 0) == -22

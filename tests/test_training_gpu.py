@@ -318,7 +318,7 @@ def test_refusals():
     t1 = _cabi.MdcTopology(_cabi.KIND_DEPLOYED, 3, 0, 3, (C.c_int32 * 4)(0, 0, 0, 0))
     assert L.mdc_trainer_create(C.byref(t1), 0, C.byref(h)) == 0
     try:      # a batch before the weights are set is a state error, not a launch on zeros
-        assert L.mdc_train_batch(h, tr._frames(x).data_ptr(), tr._targets(y, 8).data_ptr(), None, 0, 8, 1, None) == -1
+        assert L.mdc_train_batch(h, tr._frames(x).data_ptr(), tr._targets(y, 8).data_ptr(), 8, None, 0, 8, 1, None) == -1
         assert L.mdc_trainer_set_adam(h, -1.0, 0.9, 0.999, 1e-7) == -22
     finally:
         L.mdc_trainer_destroy(h)
@@ -468,3 +468,35 @@ def test_first_epoch_of_a_fresh_cnn_py_model_starts_where_the_recorded_run_did()
     h = m.fit(x[:n], to_onehot(lab[:n], 5), batch_size=1024, epochs=1, validation_data=(x[n:], to_onehot(lab[n:], 5)), seed=0)
     assert m.trainer().read(reset=False)["iterations"] == 22            # `22/22` in the recorded log
     assert abs(h.history["loss"][0] - 1.6028) < 0.02 and abs(h.history["val_loss"][0] - math.log(5)) < 0.02
+
+
+@pytest.mark.parametrize("kind,topo", CASES[:3], ids=IDS[:3])
+def test_a_shuffle_index_outside_the_data_set_is_an_error_at_read_not_a_fault(kind, topo):
+    """order_dev's VALUES are read on the device: one that names no frame of the buffers is skipped there (it adds nothing to loss
+    or gradient) and counted, and the epoch's read raises with the count.  The remaining frames' gradient is exactly the batch's
+    without them; after the reset the trainer carries on."""
+    import torch
+    n = 300
+    w = synthetic_weights(topo, seed=3, bias_scale=0.05)
+    x, y = _data(topo, n, seed=17)
+    tr = Trainer(topo, w, device=0)
+    xd, yd = tr._frames(x), tr._targets(y, n)
+    order = np.arange(n, dtype=np.int32)
+    bad = order.copy()
+    bad[[5, 77, 290]] = [n, -1, 2 ** 31 - 1]                      # one past the end, negative, far away
+    tr.read(reset=True)
+    tr.train_batch(xd, yd, torch.from_numpy(bad).cuda(), 0, n, apply=False)
+    with pytest.raises(RuntimeError, match="3 batch positions"):
+        tr.read(reset=True)
+    g_bad = tr.gradients()
+    keep = np.setdiff1d(order, [5, 77, 290])
+    tr.train_batch(xd, yd, torch.from_numpy(keep.astype(np.int32)).cuda(), 0, keep.size, apply=False)
+    r = tr.read(reset=True)                                        # clean again
+    g_ok = tr.gradients()
+    for (a, b), (c, d) in zip(g_bad, g_ok):                        # mean over 300 against mean over 297 of the same 297 frames
+        assert _rel(a * (n / keep.size), c) <= 2e-5 and _rel(b * (n / keep.size), d) <= 2e-5
+    assert r["train_frames"] == keep.size
+    L = _cabi.lib()                                                # without a shuffle the host sees the range itself
+    assert L.mdc_train_batch(tr._h, xd.data_ptr(), yd.data_ptr(), n, None, n - 4, 8, 0, None) == -22
+    assert L.mdc_trainer_evaluate(tr._h, xd.data_ptr(), yd.data_ptr(), n, None, 0, n + 1, None) == -22
+    assert L.mdc_train_batch(tr._h, xd.data_ptr(), yd.data_ptr(), -1, None, 0, 0, 0, None) == -22

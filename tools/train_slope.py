@@ -11,7 +11,7 @@ for name, topo in (("T1", Topology.deployed(3)), ("T2", Topology.deployed(10)), 
     for mode in ("grad", "eval"):
         for count in (1024, 2048, 4096, 8192, 16384, 32768, 65536):
             f = (lambda: tr.train_batch(xd, yd, None, 0, count, apply=False)) if mode == "grad" else \
-                (lambda: tr._check(tr._lib().mdc_trainer_evaluate(tr._h, xd.data_ptr(), yd.data_ptr(), None, 0, count, tr._stream())))
+                (lambda: tr._check(tr._lib().mdc_trainer_evaluate(tr._h, xd.data_ptr(), yd.data_ptr(), n, None, 0, count, tr._stream())))
             for _ in range(5): f()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
