@@ -106,10 +106,13 @@ __device__ __forceinline__ long frame_index(const int* __restrict__ order, long 
     return -1;
 }
 
+// Sum over the wave, the same bits in every lane: the DPP butterfly over each 16-lane row (no LDS crossbar: __shfl_xor compiles to
+// ds_bpermute_b32, six dependent LDS round trips per sum), then the four row sums through scalar registers in a fixed order.
 __device__ __forceinline__ float wave_allsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = row_allreduce(v, [](float a, float b) { return a + b; });
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // softmax -> Keras categorical_crossentropy on the probabilities -> gradient w.r.t. the softmax INPUT.  y: the target row.
