@@ -17,8 +17,8 @@
 //                    RECOMPUTED from the frame still in registers -- nothing but the 1 KiB frame is read per sample and
 //                    nothing per-sample is written.  Deployed nets: a lane owns a fixed set of weights (4 (+1) conv
 //                    positions x F filters x 3 classes of the dense kernel) for the whole slice, so their gradients
-//                    accumulate in its registers and only the per-frame reductions (3 class sums) cross lanes (xor
-//                    butterfly: every lane ends with the same bits).  cnn.py's net: 16-frame tiles on the f32 MFMA
+//                    accumulate in its registers and only the per-frame reductions (3 class sums) cross lanes (DPP row
+//                    butterflies + the four row sums in a fixed order: every lane ends with the same bits).  cnn.py's net: 16-frame tiles on the f32 MFMA
 //                    (see train_cnnpy_kernel).  Each wave writes ONE partial gradient vector; the shuffle of fit() is an
 //                    index array (`order`), frames are never moved.
 //   mdc_train_adam   sums the G partials in a fixed order (the result depends on (count, G) only -- no float atomics, so
