@@ -135,13 +135,18 @@ __global__ __launch_bounds__(256, 2) void deployed_q612_kernel(const void* __res
                     for (int c = 0; c < kQC; ++c)
                         acc[c] += (unsigned)pair18(ai, wq(s, f, c, 0), aq, wq(s, f, c, 1));      // sign-extended 18-bit term, 32-bit wrap
                 }
-            // wave sum (wrap-around adds commute): every lane ends up with the total
+            // wave sum (wrap-around adds commute and associate: any order gives the same bits): a DPP butterfly over each 16-lane
+            // row, then the four row sums through scalar registers -- __shfl_xor would be six dependent ds_bpermute_b32 per class
 #pragma unroll
             for (int c = 0; c < kQC; ++c) {
-                unsigned v = acc[c];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += (unsigned)__shfl_xor((int)v, off);
-                keep[c] = (lane == it) ? (int)v : keep[c];
+                int v = (int)acc[c];
+                v += __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x140 /*row_mirror*/, 0xf, 0xf, true);
+                const unsigned tot = (unsigned)__builtin_amdgcn_readlane(v, 0) + (unsigned)__builtin_amdgcn_readlane(v, 16) +
+                                     (unsigned)__builtin_amdgcn_readlane(v, 32) + (unsigned)__builtin_amdgcn_readlane(v, 48);
+                keep[c] = (lane == it) ? (int)tot : keep[c];
             }
             const int s0 = __builtin_amdgcn_readfirstlane(xi.x), s1 = __builtin_amdgcn_readfirstlane(xq.x);
             x00 = (lane == it) ? s0 : x00;
