@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void train_deployed_kernel(const float* __restr
                 }
         }
         auto scale_of = [&](int s, int f) -> float { return DROP ? (((keep >> (s * F + f)) & 1ull) ? drop.inv : 0.f) : 1.f; };
-        float xprev = __shfl_up(xv.w, 1, 64);
+        float xprev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xv.w), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
         if (lp == 0) xprev = 0.f;                                       // ZeroPadding2D((0,1)): x[h][-1] = 0
         const float xin[S] = {xprev, xv.x, xv.y, xv.z, xv.w};           // x[h][w-1]
         const float xcu[S] = {xv.x, xv.y, xv.z, xv.w, 0.f};             // x[h][w]   (x[h][128] = 0)
