@@ -18,7 +18,9 @@ included -- the stance of VTCNN2.load_results.
 """
 from __future__ import annotations
 
+import os
 import pickle
+import struct
 from typing import Dict, Iterable, List, Sequence, Tuple
 
 import numpy as np
@@ -48,6 +50,32 @@ def _latin1_bytes(text, encoding="latin1"):
     return text.encode("latin1")
 
 
+_DAMAGE = (EOFError, UnicodeError, MemoryError, OverflowError, TypeError, AttributeError, IndexError, KeyError, ImportError,
+           RecursionError, SystemError, struct.error)
+
+
+class _Bounded:
+    """The file as the unpickler sees it: a length field that asks for more bytes than the file still holds is refused BEFORE a
+    buffer of that size is read into (a flipped bit in an 8-byte length would otherwise be a multi-gigabyte request).  The C
+    unpickler's counted-bytes opcodes allocate their destination before they read: such a request either fails at once
+    (MemoryError -> UnpicklingError below) or is never touched beyond the bytes the file really has."""
+
+    def __init__(self, fd):
+        self.fd = fd
+        self.size = os.fstat(fd.fileno()).st_size
+
+    def _check(self, n):
+        if n is not None and n >= 0 and n > self.size - self.fd.tell():
+            raise pickle.UnpicklingError("pickle data was truncated (a length field runs past the end of the file)")
+
+    def read(self, n=-1):
+        self._check(n)
+        return self.fd.read(n)
+
+    def readline(self):
+        return self.fd.readline()
+
+
 class _ArraysOnly(pickle.Unpickler):
     """dict / tuple / str / int / float come without globals; arrays need exactly the reconstructors below."""
 
@@ -65,9 +93,18 @@ class _ArraysOnly(pickle.Unpickler):
 
 def load_rml2016(path: str) -> Dict[Key, np.ndarray]:
     """{(modulation, snr): float32 (n, 2, 128)} from the dataset pickle (cnn.py:42-43, without executing the file).
-    Raises pickle.UnpicklingError for a file that names any other global, ValueError for a wrong structure."""
-    with open(path, "rb") as fd:
-        obj = _ArraysOnly(fd, encoding="latin1").load()      # Python-2 str payloads -> latin-1, as the reference passes
+    Raises pickle.UnpicklingError for a file that names any other global or is damaged (truncated, bit-flipped: whatever the
+    unpickler trips over comes out as this one type, and no length field is believed beyond the file's own size), ValueError
+    for a wrong structure."""
+    try:
+        with open(path, "rb") as fd:
+            obj = _ArraysOnly(_Bounded(fd), encoding="latin1").load()      # Python-2 str payloads -> latin-1, as the reference passes
+    except UnicodeError as e:      # (a ValueError by inheritance, but it says "damaged", not "wrong structure")
+        raise pickle.UnpicklingError(f"{path}: damaged pickle ({type(e).__name__}: {e})") from e
+    except (pickle.UnpicklingError, ValueError):
+        raise
+    except _DAMAGE as e:      # what a truncated or bit-flipped pickle trips inside the unpickler: one error type for the caller
+        raise pickle.UnpicklingError(f"{path}: damaged pickle ({type(e).__name__}: {e})") from e
     if not isinstance(obj, dict) or not obj:
         raise ValueError(f"{path}: expected a non-empty dict keyed by (modulation, snr)")
     out: Dict[Key, np.ndarray] = {}
