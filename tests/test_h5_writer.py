@@ -6,7 +6,9 @@ Three independent readers judge a written file:
     image, not of the reference): a file written from the contents of a bundled checkpoint must dump to the SAME text as
     that checkpoint -- same groups, same datatypes down to string padding and character set, same attribute values,
     same data;
-  * libhdf5 through ctypes (H5Fopen / H5Dopen2 / H5Dread), as the reference's h5py would call it.
+  * libhdf5 through ctypes (H5Fopen / H5Dopen2 / H5Dread), as the reference's h5py would call it;
+  * libhdf5's own tools: h5diff against the bundled checkpoint (no differences; one changed bit is found), h5repack + h5diff
+    round trips, h5stat's accounting.
 No reference file travels: the tests that read /root/reference skip where it is absent (the GPU box)."""
 import ctypes as C
 import json
@@ -193,3 +195,57 @@ def test_shape_mismatch_is_refused(tmp_path):
         write_keras_h5(str(tmp_path / "x.h5"), topo, [(w[0][0], w[0][1]), (w[1][0][:-1], w[1][1])])
     with pytest.raises(ValueError):
         write_keras_h5(str(tmp_path / "x.h5"), topo, w[:1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# libhdf5's own tools as judges (HDF5 1.10.6 of this image; absent on a box without /opt/conda they skip):
+#   h5diff    object-by-object, attribute-by-attribute, element-by-element comparison of two files
+#   h5repack  reads EVERYTHING through the library and writes it again: a file it can repack is a file h5py can read
+#   h5stat    walks all metadata (object headers, B-trees, heaps) and accounts for the file's bytes
+# ---------------------------------------------------------------------------------------------------------------------
+def _tool(name):
+    p = shutil.which(name) or os.path.join("/opt/conda/bin", name)
+    return p if os.path.exists(p) else None
+
+
+@pytest.mark.skipif(_tool("h5diff") is None, reason="no h5diff in this image")
+@pytest.mark.parametrize("name", H5_NAMES)
+def test_h5diff_finds_no_difference_to_the_reference_checkpoint(reference_dir, tmp_path, name):
+    ref = os.path.join(reference_dir, name + ".wts.h5")
+    out = str(tmp_path / "rewritten.h5")
+    _rewrite(ref, out)
+    r = subprocess.run([_tool("h5diff"), "-c", ref, out], capture_output=True, text=True)      # rc 0: no differences; -c: list what cannot be compared
+    assert r.returncode == 0 and "not comparable" not in r.stdout and not r.stderr.strip(), r.stdout + r.stderr
+    # ... and it does see one when there is one (a single weight changed in the last bit)
+    ck = load_keras_h5(ref)
+    topo = Topology.from_keras_config(ck.model_config)
+    weighted = [n for n in ck.layer_names if ck.weights[n]]
+    w = [(ck.weights[n][0][1].copy(), ck.weights[n][1][1].copy()) for n in weighted]
+    w[1][0][5, 1] = np.nextafter(w[1][0][5, 1], np.float32(9))
+    names = [l["config"]["name"] for l in ck.model_config["config"]["layers"][1:]]
+    write_keras_h5(out, topo, w, optimizer=_optimizer_of(H5File(ref), weighted), layer_names=names, model_name=ck.model_config["config"]["name"])
+    r = subprocess.run([_tool("h5diff"), ref, out], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 differences found" in r.stdout, r.stdout
+
+
+@pytest.mark.skipif(_tool("h5repack") is None or _tool("h5diff") is None or _tool("h5stat") is None, reason="no HDF5 tools in this image")
+@pytest.mark.parametrize("kind", ["deployed3", "deployed10", "cnnpy", "vtcnn2"])
+def test_libhdf5_repacks_and_accounts_for_every_topologys_file(tmp_path, kind):
+    topo = {"deployed3": Topology.deployed(3), "deployed10": Topology.deployed(10), "cnnpy": Topology.cnnpy(10, 10, 5),
+            "vtcnn2": Topology.vtcnn2(11)}[kind]
+    w = synthetic_weights(topo, seed=2, bias_scale=0.1)
+    for opt in (None, {"iterations": 41, "m": w, "v": w}):
+        src, dst = str(tmp_path / "w.h5"), str(tmp_path / "repacked.h5")
+        if os.path.exists(dst):
+            os.remove(dst)
+        write_keras_h5(src, topo, w, optimizer=opt)
+        r = subprocess.run([_tool("h5repack"), src, dst], capture_output=True, text=True)
+        assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+        r = subprocess.run([_tool("h5diff"), src, dst], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        back = load_keras_h5(dst)                                     # and our reader takes libhdf5's rewrite of our file
+        for (k, b), lname in zip(w, [n for n in back.layer_names if back.weights[n]]):
+            assert np.array_equal(back.weights[lname][0][1], k) and np.array_equal(back.weights[lname][1][1], b)
+        r = subprocess.run([_tool("h5stat"), src], capture_output=True, text=True)
+        assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+        assert f"# of unique datasets: {2 * len(topo.layer_shapes) + (1 + 4 * len(topo.layer_shapes) if opt else 0)}" in r.stdout, r.stdout[:600]
