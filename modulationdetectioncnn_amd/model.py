@@ -180,7 +180,9 @@ class VTCNN2:
             out.append((k, b))
         self._weights = out
         self._release()
-        self._drop_trainer()        # weights set from outside: the optimizer state that went with the old ones is void
+        t = getattr(self, "_trainer", None)
+        if t is not None:           # as in Keras: set_weights / load_weights replace the layers' variables, the optimizer keeps its
+            t.set_weights(out)      # slots (Adam's m, v, iterations) -- cnn.py:147 reloads the best epoch into a compiled model
 
     def get_weights(self) -> Weights:
         if self._weights is None:
