@@ -67,7 +67,7 @@ class VTCNN2:
         self.dtype = dtype
         self.fp8_input_absmax = fp8_input_absmax
         self.fp8_bf16_features = bool(fp8_bf16_features)
-        self.fp8_feature_absmax = fp8_feature_absmax
+        self._fp8_feature_absmax = fp8_feature_absmax
         if self.fp8_bf16_features and not (topology.kind == "vtcnn2" and dtype == "fp8"):
             raise ValueError("fp8_bf16_features is an option of the vtcnn2 family's fp8 mode")
         self._lib_variant = _lib_variant
@@ -299,6 +299,20 @@ class VTCNN2:
         self._handle = h
         return h
 
+    @property
+    def fp8_feature_absmax(self) -> Optional[float]:
+        """The caller's bound on the conv2 features for the E4M3 feature scale (None: the estimate from the weights).  Setting it
+        re-packs the engine at its next use."""
+        return self._fp8_feature_absmax
+
+    @fp8_feature_absmax.setter
+    def fp8_feature_absmax(self, value: Optional[float]) -> None:
+        if value is not None and not float(value) > 0.0:
+            raise ValueError("fp8_feature_absmax must be positive (or None)")
+        self._fp8_feature_absmax = None if value is None else float(value)
+        if getattr(self, "_handle", None) is not None:
+            self._release()
+
     def calibrate_fp8_features(self, X, headroom: float = 2.0) -> float:
         """Calibration of the fp8 mode's E4M3 feature scale on a sample batch: the same weights in bf16 mode, the
         conv tap of X, `headroom` x its largest value -> mdc_set_fp8_feature_absmax at the next (re-)finalize.  Returns the
@@ -311,8 +325,7 @@ class VTCNN2:
         probe._release()
         if not top > 0.0:
             raise ValueError("the sample produced no positive conv2 feature")
-        self.fp8_feature_absmax = headroom * top
-        self._release()
+        self.fp8_feature_absmax = headroom * top      # (the setter releases the packed engine)
         return self.fp8_feature_absmax
 
     def _release(self) -> None:

@@ -97,3 +97,30 @@ def test_random_call_sequences_keep_the_model_consistent(tmp_path, seed):
             m.compile(loss="categorical_crossentropy", optimizer="adam", lr=2e-3)
             opt = T.KerasAdam([t.shape for t in T.flatten_weights(w)], lr=2e-3)
         _check(m, kind, w, rng)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
+def test_a_reused_vtcnn2_model_equals_a_fresh_one(dtype):
+    """The canonical VT-CNN2's engine packs its weights for the dtype (bf16 hi/lo splits, E4M3 with scales derived from the weights or
+    from a calibration): after any sequence of set_weights / calibrate / predict at other sizes, a model must give the bits a
+    freshly built one with the same weights and settings gives."""
+    topo = Topology.vtcnn2(11)
+    rng = np.random.default_rng(7)
+    x = synthetic_frames(300, seed=3)
+    m = VTCNN2(topo, device=0, dtype=dtype)
+    for round_ in range(3):
+        w = synthetic_weights(topo, seed=50 + round_)
+        m.set_weights(w)
+        for n in rng.choice([1, 16, 17, 255, 300], size=2):
+            m.predict(x[:int(n)])                                      # other sizes first: small-batch forms, other workspaces
+        absmax = None
+        if dtype == "fp8" and round_ != 1:
+            absmax = m.calibrate_fp8_features(x[:64])
+            m.predict(x[:5])
+        fresh = VTCNN2(topo, device=0, dtype=dtype, **({"fp8_feature_absmax": absmax} if absmax is not None else {}))
+        fresh.set_weights(w)
+        if dtype == "fp8" and round_ == 1:
+            m.fp8_feature_absmax = None                                # back to the statistical estimate from the weights
+        a, b = m.predict(x), fresh.predict(x)
+        assert np.array_equal(a, b), (dtype, round_, np.abs(a - b).max())
+        assert np.array_equal(m.predict_classes(x), fresh.predict_classes(x))
