@@ -87,6 +87,16 @@ class VTCNN2:
         # workspace, +1.5 %: one launch of each kernel instead of sixteen) -- bench.py's headline does, and says so.
         self.default_chunk = 1 << 16 if topology.kind == "vtcnn2" else 1 << 22
 
+    # what the packed engine was built from cannot change under it
+    _FIXED = ("topology", "dtype", "fp8_bf16_features", "_lib_variant")
+
+    def __setattr__(self, name, value):
+        if name in VTCNN2._FIXED and name in self.__dict__:
+            raise AttributeError(f"{name} is fixed at construction: build another VTCNN2")
+        if name == "fp8_input_absmax" and self.__dict__.get("_handle") is not None:
+            self._release()                 # re-packed with the new activation scale at the next use
+        object.__setattr__(self, name, value)
+
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_h5(cls, path: str, **kw) -> "VTCNN2":

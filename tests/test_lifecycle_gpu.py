@@ -124,3 +124,17 @@ def test_a_reused_vtcnn2_model_equals_a_fresh_one(dtype):
         a, b = m.predict(x), fresh.predict(x)
         assert np.array_equal(a, b), (dtype, round_, np.abs(a - b).max())
         assert np.array_equal(m.predict_classes(x), fresh.predict_classes(x))
+
+
+def test_what_the_engine_was_built_from_cannot_change_under_it():
+    topo = Topology.vtcnn2(3)
+    x = synthetic_frames(64, seed=2, sigma=0.004)
+    m = VTCNN2.synthetic(topo, seed=1, device=0, dtype="fp8")
+    a = m.predict(x)
+    for name, value in (("dtype", "bf16"), ("topology", Topology.deployed(3)), ("fp8_bf16_features", True)):
+        with pytest.raises(AttributeError, match="fixed at construction"):
+            setattr(m, name, value)
+    m.fp8_input_absmax = 0.5                                           # allowed: a coarser activation scale, re-packed at the next use
+    b = m.predict(x)
+    fresh = VTCNN2.synthetic(topo, seed=1, device=0, dtype="fp8", fp8_input_absmax=0.5)
+    assert np.array_equal(b, fresh.predict(x)) and not np.array_equal(a, b)
