@@ -29,6 +29,25 @@ __device__ __forceinline__ float row_allreduce(float v, Op op) {
     return v;
 }
 
+// One dependent MFMA chain over a staged row of 256 floats: acc += A[row][k] B[k][col], k-steps 0 .. 63 in order (the order is the
+// result).  xrow = &image[row * ld + g]; the A operands are requested from LDS a pair of k-steps AHEAD of the MFMAs that use them,
+// pinned with sched_barrier: left alone, hipcc reads each pair into the same two registers right after the MFMAs that consumed the
+// last one and waits out the whole LDS latency in front of the next two (dense_chain.hip; profiles/r05_dense_chain2_ab.log).
+__device__ __forceinline__ f32x4 chain_k256(const float* xrow, const float (&w)[64], f32x4 acc) {
+    float a_cur[2] = {xrow[0], xrow[4]}, a_nxt[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j + 1 < 32) { a_nxt[0] = xrow[8 * (j + 1)]; a_nxt[1] = xrow[8 * (j + 1) + 4]; }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0], w[2 * j], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1], w[2 * j + 1], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur[0] = a_nxt[0];
+        a_cur[1] = a_nxt[1];
+    }
+    return acc;
+}
+
 // softmax + first-max argmax over the classes (the 16 lanes of a DPP row) of a 16-row tile: lane (class = fr), rows
 // 4g + r hold the pre-softmax values z[r].  int(np.argmax(test_Y_hat[i,:])) (cnn.py:209): the FIRST index attaining the
 // maximum of the PROBABILITIES as returned (slightly different logits can round to the same probability).

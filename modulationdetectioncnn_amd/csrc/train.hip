@@ -412,11 +412,22 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
         __syncthreads();
         // ---- forward
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        {   // A operands a pair of k-steps ahead of the MFMAs that use them (pinned: hipcc otherwise re-uses two registers and waits
+            // out the LDS latency in front of every four MFMAs -- one wave per SIMD here, nothing else to fill it; dense_chain.hip)
+            float a_cur[2] = {xs[fr * kT4Xld + g], xs[fr * kT4Xld + 4 + g]}, a_nxt[2] = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const float a = xs[fr * kT4Xld + 4 * i + g];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Mw[0][i], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Mw[1][i], acc[1], 0, 0, 0);
+            for (int j = 0; j < 32; ++j) {
+                if (j + 1 < 32) { a_nxt[0] = xs[fr * kT4Xld + 8 * (j + 1) + g]; a_nxt[1] = xs[fr * kT4Xld + 8 * (j + 1) + 4 + g]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u], Mw[0][2 * j + u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u], Mw[1][2 * j + u], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                a_cur[0] = a_nxt[0];
+                a_cur[1] = a_nxt[1];
+            }
         }
         f32x4 pre[2], a1[2];
 #pragma unroll
@@ -497,14 +508,27 @@ __global__ __launch_bounds__(64) void train_cnnpy_kernel(const float* __restrict
                 for (int r = 0; r < 4; ++r) dpre[jt][r] = pre[jt][r] > 0.f ? (DROP ? da[r] * m0[jt][r] : da[r]) : 0.f;
                 gcb[jt] += (dpre[jt][0] + dpre[jt][1]) + (dpre[jt][2] + dpre[jt][3]);
             }
+            {   // A[row = input 16T + fr][k = frame 4g + i]: the next input tile's four values are read before this one's MFMAs issue
+                float x_cur[4], x_nxt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int T = 0; T < 16; ++T)
+                for (int i = 0; i < 4; ++i) x_cur[i] = xs[(4 * g + i) * kT4Xld + fr];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float xa = xs[(4 * g + i) * kT4Xld + 16 * T + fr];      // A[row = input 16T + fr][k = frame 4g + i]
-                    dM[T][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, dpre[0][i], dM[T][0], 0, 0, 0);
-                    dM[T][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, dpre[1][i], dM[T][1], 0, 0, 0);
+                for (int T = 0; T < 16; ++T) {
+                    if (T + 1 < 16) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) x_nxt[i] = xs[(4 * g + i) * kT4Xld + 16 * (T + 1) + fr];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dM[T][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x_cur[i], dpre[0][i], dM[T][0], 0, 0, 0);
+                        dM[T][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x_cur[i], dpre[1][i], dM[T][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x_cur[i] = x_nxt[i];
                 }
+            }
         }
         __syncthreads();      // xs / ys are rewritten by the next tile
     }

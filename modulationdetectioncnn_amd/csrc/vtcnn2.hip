@@ -340,10 +340,7 @@ __global__ __launch_bounds__(512) void vt_dense1_f32_kernel(const float* __restr
         const float b2 = w2pack[64 * 64 + 16 * 64 + fr];
         __syncthreads();
         if (wv < ROWS / 16) {      // (64-row tiles: waves 0 .. 3; wave-uniform)
-            f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(wv * 16 + fr) * kChainXld + 4 * i + fq], w2[i], a2, 0, 0, 0);
+            const f32x4 a2 = chain_k256(xs + (wv * 16 + fr) * kChainXld + fq, w2, f32x4{0.f, 0.f, 0.f, 0.f});
             f32x4 z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = a2[r] + b2;

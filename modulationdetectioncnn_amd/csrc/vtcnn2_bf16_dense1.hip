@@ -191,10 +191,7 @@ __device__ __forceinline__ void d1_epilogue(f32x4 (&acc)[8][4], unsigned char* s
                             xs[(i * 16 + fg * 4 + r) * kChainXld + wc * 64 + j * 16 + fr] = fmaxf(acc[i][j][r] + bias1[j], 0.f);
             }
             __syncthreads();
-            f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(wv * 16 + fr) * kChainXld + 4 * i + fg], w2[i], a2, 0, 0, 0);
+            const f32x4 a2 = chain_k256(xs + (wv * 16 + fr) * kChainXld + fg, w2, f32x4{0.f, 0.f, 0.f, 0.f});
             f32x4 z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = a2[r] + b2;
