@@ -70,7 +70,8 @@ __device__ __forceinline__ void chain_glds16_s(const void* sbase, unsigned lane_
 //  * the DMA addresses are a scalar base + a constant per-lane offset, and taps / ReLU flags are template parameters: the tile's
 //    non-MFMA instructions share the SIMD's issue with the MFMAs (a no-load probe runs at 0.73 of the full kernel's time), so
 //    every vector instruction taken out of the tile counts.
-// 2.63e9 -> 3.4e9 -> 3.9-4.0e9 frames/s on one box.  What is left: ~360 vector instructions of tail per tile beside 140 MFMAs.
+// 2.63e9 -> 3.4e9 -> 4.2e9 frames/s on one box (with the fused-DPP softmax reductions of dense_chain_common.h).  What is left:
+// ~300 vector instructions of tail per tile beside 140 MFMAs.
 // TAPS: the instantiation that also writes the layer taps (CNN.ipynb cell 17's sub-models); the batch path's has none of their
 // address arithmetic and branches in its tail.  The three-layer chain is cnn.py's net: ReLU after layers 1 and 2 (cnn.py:108-110).
 template <int T1, int NL, bool TAPS>

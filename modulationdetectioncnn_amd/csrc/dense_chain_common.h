@@ -29,6 +29,24 @@ __device__ __forceinline__ float row_allreduce(float v, Op op) {
     return v;
 }
 
+// max / min over the 16 lanes of a DPP row with the row operand folded INTO the instruction (v_max_f32_dpp): hipcc fuses the add
+// butterfly above but emits v_mov_b32_dpp + v_max_f32 for these -- four instructions more per reduction, and the softmax below is
+// three of them per row in tails where every vector instruction competes with the MFMAs for the SIMD's issue.  Same values.
+// (s_nop 1: a DPP read of a VGPR needs two wait states behind the vector instruction that wrote it, and hipcc pads that hazard
+// for its own instructions only)
+#define MDC_DPP_STEP(OP, CTRL) asm("s_nop 1\n\tv_" OP "_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(v)); v = t;
+__device__ __forceinline__ float row_allmax(float v) {
+    float t;
+    MDC_DPP_STEP("max", "quad_perm:[1,0,3,2]") MDC_DPP_STEP("max", "quad_perm:[2,3,0,1]") MDC_DPP_STEP("max", "row_half_mirror") MDC_DPP_STEP("max", "row_mirror")
+    return v;
+}
+__device__ __forceinline__ float row_allmin(float v) {
+    float t;
+    MDC_DPP_STEP("min", "quad_perm:[1,0,3,2]") MDC_DPP_STEP("min", "quad_perm:[2,3,0,1]") MDC_DPP_STEP("min", "row_half_mirror") MDC_DPP_STEP("min", "row_mirror")
+    return v;
+}
+#undef MDC_DPP_STEP
+
 // One dependent MFMA chain over a staged row of 256 floats: acc += A[row][k] B[k][col], k-steps 0 .. 63 in order (the order is the
 // result).  xrow = &image[row * ld + g]; the A operands are requested from LDS a pair of k-steps AHEAD of the MFMAs that use them,
 // pinned with sched_barrier: left alone, hipcc reads each pair into the same two registers right after the MFMAs that consumed the
@@ -58,13 +76,13 @@ __device__ __forceinline__ void chain_softmax_store(const f32x4& z, int fr, int 
     for (int r = 0; r < 4; ++r) {
         const long row = row0 + 4 * g + r;
         const float zz = cls ? z[r] : -INFINITY;
-        const float mx = row_allreduce(zz, [](float a, float b) { return fmaxf(a, b); });
+        const float mx = row_allmax(zz);
         const float e = cls ? expf(zz - mx) : 0.f;
         const float sum = row_allreduce(e, [](float a, float b) { return a + b; });
         const float pv = e / sum;
-        const float pmx = row_allreduce(cls ? pv : -1.f, [](float a, float b) { return fmaxf(a, b); });
+        const float pmx = row_allmax(cls ? pv : -1.f);
         const float cand = (cls && pv == pmx) ? (float)fr : 1e9f;
-        const float arg = row_allreduce(cand, [](float a, float b) { return fminf(a, b); });
+        const float arg = row_allmin(cand);
         if (row < n) {
             if (cls) {
                 if (probs) probs[row * n_out + fr] = pv;
