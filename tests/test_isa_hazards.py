@@ -83,3 +83,25 @@ def test_no_product_kernel_uses_scratch():
     assert any("deployed_q612_kernel" in k for k in meta) and any("train_deployed_kernel" in k for k in meta)
     bad = {k: r for k, r in meta.items() if r["scratch"] != 0 or r["vgpr_spill"] != 0}
     assert not bad, bad
+
+
+def _serialised_lds_mfma(isa):
+    """Count `ds_read*; s_waitcnt lgkmcnt(0); v_mfma*` triples: an MFMA stalled on an LDS read issued just before it."""
+    return sum(1 for a, b, c in zip(isa, isa[1:], isa[2:]) if a.startswith("ds_read") and b.startswith("s_waitcnt") and "lgkmcnt(0)" in b
+               and c.startswith("v_mfma"))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+@pytest.mark.parametrize("src,kernel,chain_mfmas", [("dense_chain.hip", "dense_chain_kernelILi2ELi3ELb0E", 128), ("dense_chain.hip", "dense_chain_kernelILi1ELi1ELb0E", 64),
+                                                    ("train.hip", "train_cnnpy_kernelILb1ELb0E", 256)])
+def test_layer_1_mfma_chains_do_not_wait_out_their_lds_reads(src, kernel, chain_mfmas):
+    """Round 5: hipcc read each pair of layer-1 A operands into the SAME two registers right after the MFMAs that consumed the last
+    pair, then waited `lgkmcnt(0)` in front of the next group -- 31 exposed LDS round trips per 16-row tile in cnn.py's net.  The
+    loops request the next pair before the current MFMAs issue (pinned with sched_barrier): in the ISA the long chains must wait
+    with a COUNTED lgkmcnt, and a read directly in front of `lgkmcnt(0)` + MFMA may only remain in the short tail layers."""
+    lint = _tool("lint_async_hazards")
+    isa = lint.kernel_isa(os.path.join(ROOT, "modulationdetectioncnn_amd", "csrc", src), kernel)
+    assert sum(1 for x in isa if x.startswith("v_mfma_f32_16x16x4")) >= chain_mfmas
+    counted = sum(1 for a, b in zip(isa, isa[1:]) if a.startswith("s_waitcnt") and "lgkmcnt(1)" in a and b.startswith("v_mfma"))
+    assert counted >= chain_mfmas // 8, counted                     # the pipelined groups wait for the OLDER read only
+    assert _serialised_lds_mfma(isa) <= 10, _serialised_lds_mfma(isa)      # (before: 31 in layer 1 alone)
