@@ -763,9 +763,16 @@ def main(argv=None, script=None):
                     continue
                 try:
                     em, ex, ep, elab, en_n, eel = run_workload(en, device, 5, 2)
+                    # an extra leg is the MEDIAN of three 5-step regions: a box now and then stalls one launch for tens of
+                    # milliseconds (seen on the training leg and, once, here: 25.0 ms per step around 18.8 ms of kernels), and a
+                    # 5-step total has nothing to absorb that with.  The headline above keeps the contract's single K-step region.
+                    from modulationdetectioncnn_amd.sharding import timed_region
+                    more = [timed_region(lambda: em.forward_device(ex, probs=ep, labels=elab, batch_size=em.bench_chunk), 5, 0,
+                                         sync=torch.cuda.synchronize, device=ex.device) for _ in range(2)]
+                    eel = sorted([eel] + more)[1]
                     erl, _ = dominant_roofline(em, ex, ep, elab, 3)
                     extras.append({"workload": en, "value": en_n * 5 / eel, "unit": "frames/s", "ms_per_step": eel / 5 * 1e3,
-                                   "dtype": WORKLOADS[en][3], "roofline": erl})
+                                   "timing": "median of three 5-step regions", "dtype": WORKLOADS[en][3], "roofline": erl})
                     del em, ex, ep, elab
                     torch.cuda.empty_cache()
                 except Exception as e:     # an extra leg never hides the headline
