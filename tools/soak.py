@@ -18,6 +18,9 @@ CASES = (  # (topology, dtype, frame counts): every small-batch form, the batch 
     ("deployed10", "f16", (70001,)),
     ("deployed3", "fp8", (70001,)),
     ("deployed3", "f32", (1, 70001)),
+    # cnn.py's literal net (dense_chain<2,3>): four k-blocks per tile refilled progressively behind counted vmcnt waits (round 5);
+    # one tile per wave, ragged last tiles, and enough tiles that every wave walks several with a next tile in flight
+    ("cnnpy", "f32", (1, 16, 17, 1000, 70001, 1 << 18, 1 << 20)),
 )
 
 
@@ -26,7 +29,7 @@ def run(reps=200, cases=CASES, device=0, log=print):
     from modulationdetectioncnn_amd import VTCNN2, Topology, synthetic_frames
     bad = []
     for topo, dtype, sizes in cases:
-        m = VTCNN2.synthetic(Topology.vtcnn2(11) if topo == "vtcnn2" else topo, device=device, dtype=dtype)
+        m = VTCNN2.synthetic(Topology.vtcnn2(11) if topo == "vtcnn2" else Topology.cnnpy(10, 10, 5) if topo == "cnnpy" else topo, device=device, dtype=dtype)
         for n in sizes:
             x = synthetic_frames(n, seed=n, device=f"cuda:{device}")
             p0, l0, _ = m.forward_device(x)
